@@ -1,0 +1,58 @@
+"""CPU: known-answer tests that pin the restated librosa.stft semantics (oracle/stft.py).
+librosa itself is not installable offline -> "parity unpinned" against it; these
+tests pin the documented algorithm (window, centring, frame count, bin mapping)."""
+import numpy as np
+
+from oracle.stft import hann_periodic, log_power_spectrogram, stft_complex, stft_window, trim_audio
+
+
+def test_shapes_for_reference_lengths():
+    # reference: W = 1 + (int(audio_length*24000) - 1)//120  (dataset.py:439,483-493)
+    for sec, W in ((1.279, 256), (1.28, 256), (2.1, 420), (4.0, 800)):
+        L = int(sec * 24000)
+        S = log_power_spectrogram(np.zeros(L, dtype=np.float32))
+        assert S.shape == (256, W) and S.dtype == np.float32
+        assert np.allclose(S, np.log(np.float32(1e-6)))
+
+
+def test_window_layout():
+    w = stft_window()
+    assert w.shape == (511,) and w[:135].sum() == 0 and w[375:].sum() == 0
+    assert w[135] == 0.0 and np.isclose(w[135 + 120], 1.0)          # periodic hann: w[0]=0, peak at n/2
+    assert np.allclose(w[135:375], hann_periodic(240))
+    assert np.count_nonzero(w) == 239
+
+
+def test_pure_tone_bin_and_amplitude():
+    sr, L, k0 = 24000, 30695, 40
+    f = k0 * sr / 511.0
+    t = np.arange(L) / sr
+    y = (0.5 * np.cos(2 * np.pi * f * t)).astype(np.float32)
+    S = np.abs(stft_complex(y))
+    mid = S[:, 20:-20]                                              # away from the zero-padded edges
+    assert (mid.argmax(axis=0) == k0).all()
+    # |X[k0]| = A/2 * sum(window) for an on-bin tone
+    assert np.allclose(mid[k0], 0.25 * hann_periodic(240).sum(), rtol=2e-3)
+
+
+def test_parseval_per_frame():
+    rng = np.random.RandomState(0)
+    y = rng.randn(30695).astype(np.float32) * 0.1
+    X = stft_complex(y).astype(np.complex128)
+    ypad = np.pad(y.astype(np.float64), 255)
+    w = stft_window()
+    for t in (0, 5, 100, 255):
+        fr = w * ypad[t * 120: t * 120 + 511]
+        # full-spectrum energy from the one-sided rfft of an odd-length frame
+        e = np.abs(X[0, t]) ** 2 + 2 * (np.abs(X[1:, t]) ** 2).sum()
+        assert np.isclose(e / 511.0, (fr ** 2).sum(), rtol=1e-5)
+
+
+def test_trim_clamps_and_centres():
+    a = np.arange(100000, dtype=np.float32)
+    seg, start_sec = trim_audio(a, frame_idx=120, audio_length=1.279)   # 2.0 s centre
+    assert len(seg) == 30695 and seg[0] == int((2.0 - 0.6395) * 24000)
+    seg, _ = trim_audio(a, frame_idx=0, audio_length=1.279)
+    assert seg[0] == 0
+    seg, _ = trim_audio(a, frame_idx=60 * 100, audio_length=1.279)
+    assert seg[-1] == 99999
