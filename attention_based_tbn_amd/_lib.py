@@ -1,0 +1,121 @@
+"""ctypes binding of libtbn_hip.so (include/tbn_hip.h).  There is NO CPU fallback: if the
+library is missing or a call fails, the product path raises."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtbn_hip.so")
+
+c_fp = C.c_void_p   # device pointers are passed as integers (tensor.data_ptr())
+c_i = C.c_int
+c_sz = C.c_size_t
+c_f = C.c_float
+
+
+class ConvInfo(C.Structure):
+    _fields_ = [("name", C.c_char * 64), ("cin", c_i), ("cout", c_i), ("ksize", c_i), ("stride", c_i),
+                ("pad", c_i), ("weight_offset", c_sz), ("channel_offset", c_sz)]
+
+
+class BackboneParams(C.Structure):
+    _fields_ = [("weight", c_fp), ("bias", c_fp), ("gamma", c_fp), ("beta", c_fp), ("running_mean", c_fp),
+                ("running_var", c_fp), ("momentum", c_f), ("eps", c_f)]
+
+
+class BackboneGrads(C.Structure):
+    _fields_ = [("dweight", c_fp), ("dbias", c_fp), ("dgamma", c_fp), ("dbeta", c_fp), ("bn_grad_layers", c_i)]
+
+
+# name -> (restype, argtypes); every symbol declared in include/tbn_hip.h
+SIGNATURES = {
+    "tbn_version": (c_i, []),
+    "tbn_last_error": (C.c_char_p, []),
+    "tbn_backbone_plan_create": (c_i, [c_i, c_i, c_i, c_i, C.POINTER(C.c_void_p)]),
+    "tbn_backbone_plan_destroy": (None, [C.c_void_p]),
+    "tbn_backbone_num_convs": (c_i, [C.c_void_p]),
+    "tbn_backbone_conv_info": (c_i, [C.c_void_p, c_i, C.POINTER(ConvInfo)]),
+    "tbn_backbone_weight_floats": (c_sz, [C.c_void_p]),
+    "tbn_backbone_channel_floats": (c_sz, [C.c_void_p]),
+    "tbn_backbone_workspace_bytes": (c_sz, [C.c_void_p, c_i]),
+    "tbn_backbone_out_shape": (c_i, [C.c_void_p, C.POINTER(c_i), C.POINTER(c_i), C.POINTER(c_i)]),
+    "tbn_backbone_forward": (c_i, [C.c_void_p, c_i, c_fp, C.POINTER(BackboneParams), c_fp, c_sz,
+                                   C.POINTER(C.c_void_p), c_fp]),
+    "tbn_backbone_backward": (c_i, [C.c_void_p, c_fp, C.POINTER(BackboneParams), C.POINTER(BackboneGrads), c_fp,
+                                    c_sz, c_fp]),
+    "tbn_conv2d_fwd": (c_i, [c_fp, c_i, c_fp, c_fp, c_fp, c_i] + [c_i] * 10 + [c_fp, c_fp, c_fp, c_fp]),
+    "tbn_conv2d_stat_tiles": (c_i, [c_i] * 8),
+    "tbn_conv2d_dgrad": (c_i, [c_fp, c_i, c_fp, c_fp, c_i] + [c_i] * 9 + [c_fp, c_fp]),
+    "tbn_conv2d_wgrad_workspace_floats": (c_sz, [c_i] * 8),
+    "tbn_conv2d_wgrad": (c_i, [c_fp, c_i, c_fp, c_i, c_fp] + [c_i] * 8 + [c_fp, c_fp]),
+    "tbn_linear_fwd": (c_i, [c_fp, c_i, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp]),
+    "tbn_linear_dgrad": (c_i, [c_fp, c_i, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp, c_fp]),
+    "tbn_linear_wgrad_workspace_floats": (c_sz, [c_i, c_i, c_i]),
+    "tbn_linear_wgrad": (c_i, [c_fp, c_i, c_fp, c_i, c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp]),
+    "tbn_bn_workspace_floats": (c_sz, [c_i, c_i]),
+    "tbn_bn_relu_train_fwd": (c_i, [c_fp, c_i, c_i, c_fp, c_fp, c_fp, c_fp, c_f, c_f, c_fp, c_fp, c_fp, c_fp, c_fp,
+                                    c_i, c_fp, c_fp]),
+    "tbn_bn_relu_train_bwd": (c_i, [c_fp, c_i, c_fp, c_i, c_i, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp]),
+    "tbn_maxpool3_fwd": (c_i, [c_fp, c_i, c_fp, c_i, c_fp] + [c_i] * 8 + [c_fp]),
+    "tbn_maxpool3_bwd": (c_i, [c_fp, c_i, c_fp, c_fp, c_i] + [c_i] * 9 + [c_fp]),
+    "tbn_avgpool3_fwd": (c_i, [c_fp, c_i, c_fp, c_i] + [c_i] * 5 + [c_fp]),
+    "tbn_spatial_mean_fwd": (c_i, [c_fp, c_i, c_fp, c_i] + [c_i] * 5 + [c_fp]),
+    "tbn_spatial_mean_bwd": (c_i, [c_fp, c_i, c_fp, c_i] + [c_i] * 5 + [c_fp]),
+    "tbn_pe_concat_fwd": (c_i, [c_fp, c_i, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp]),
+    "tbn_groupnorm_fwd": (c_i, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_f, c_fp]),
+    "tbn_groupnorm_bwd": (c_i, [c_fp] * 8 + [c_i] * 4 + [c_fp]),
+    "tbn_colsum": (c_i, [c_fp, c_i, c_fp, c_i, c_i, c_fp]),
+    "tbn_mha_q1_fwd": (c_i, [c_fp] * 6 + [c_i] * 4 + [c_f, c_fp]),
+    "tbn_mha_q1_bwd": (c_i, [c_fp] * 8 + [c_i] * 4 + [c_f, c_fp]),
+    "tbn_weighted_sum_fwd": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp]),
+    "tbn_weighted_sum_bwd": (c_i, [c_fp, c_i, c_fp, c_fp, c_i, c_i, c_i, c_fp]),
+    "tbn_segment_mean_fwd": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_fp]),
+    "tbn_segment_mean_bwd": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_fp]),
+    "tbn_mul_mask": (c_i, [c_fp, c_fp, c_fp, c_sz, c_fp]),
+    "tbn_relu_mask_bwd": (c_i, [c_fp, c_fp, c_fp, c_fp, c_sz, c_fp]),
+    "tbn_stft_twiddle_floats": (c_sz, []),
+    "tbn_stft_make_twiddle": (c_i, [c_fp]),
+    "tbn_stft_logpower": (c_i, [c_fp, c_i, c_i, c_fp, c_fp, c_f, c_fp]),
+}
+
+_lib = None
+
+
+class TbnHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """The loaded library; raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise TbnHipError(
+                f"{LIB_PATH} not found: build it with `python -m attention_based_tbn_amd.build` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the TBN hot path.")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)   # AttributeError if a declared symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().tbn_last_error()
+        raise TbnHipError(f"{what} failed (rc={rc}): {msg.decode() if msg else ''}")
+
+
+def call(name, *args):
+    """Invoke a status-returning entry point and raise on error."""
+    check(getattr(lib(), name)(*args), name)
+
+
+def stream_ptr():
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t):
+    return 0 if t is None else t.data_ptr()

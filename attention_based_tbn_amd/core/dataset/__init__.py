@@ -1,0 +1,2 @@
+from .sampler import SegmentSampler, frame_span, get_offsets  # noqa: F401
+from .spectrogram import Spectrogram, trim_audio_window  # noqa: F401

@@ -1,0 +1,67 @@
+"""Data parallelism for the TBN hot path: one process per GPU, RCCL all-reduce over xGMI.
+
+Replaces reference core/models/dataparallel.py:4-6 (single-process nn.DataParallel: per-step
+parameter broadcast + scatter/gather + reduce to GPU 0).  Here every rank holds a replica, runs
+the full forward/backward on its own shard of the clips (per-replica BatchNorm statistics, as
+nn.DataParallel's chunks had) and gradients are averaged with ONE collective per parameter
+tensor -- the backbones keep their parameters in a few flat tensors, so that is a handful of
+large all-reduces (~41 MB per backbone) launched as soon as each backbone's backward finishes and
+overlapped with the rest of the backward on RCCL's stream.  No collective on the data path.
+
+`DataParallel(model)` keeps the reference surface: `.module`, `forward`, `get_loss(...)`,
+`state_dict()` of the wrapped model under the `module.` prefix.
+"""
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+
+class DataParallel(nn.Module):
+    def __init__(self, module, device_ids=None, process_group=None, broadcast_parameters=True):
+        super().__init__()
+        self.module = module
+        self.device_ids = device_ids
+        self.process_group = process_group
+        self._pending = []
+        self._callback_queued = False
+        self._hooks = []
+        self.world_size = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        if self.world_size > 1:
+            if broadcast_parameters:
+                self.broadcast_parameters()
+            for p in self.module.parameters():
+                if p.requires_grad:
+                    self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad_ready))
+
+    def broadcast_parameters(self, src=0):
+        """rank `src`'s parameters and buffers become everyone's (once, at wrap time)"""
+        with torch.no_grad():
+            for t in list(self.module.parameters()) + list(self.module.buffers()):
+                dist.broadcast(t, src, group=self.process_group)
+
+    def _on_grad_ready(self, p):
+        g = p.grad
+        if dist.get_backend(self.process_group) == "nccl":
+            work = dist.all_reduce(g, op=dist.ReduceOp.AVG, group=self.process_group, async_op=True)
+            self._pending.append((work, None))
+        else:
+            work = dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.process_group, async_op=True)
+            self._pending.append((work, g))
+        if not self._callback_queued:
+            self._callback_queued = True
+            torch.autograd.Variable._execution_engine.queue_callback(self.finish_gradient_sync)
+
+    def finish_gradient_sync(self):
+        """wait for the in-flight all-reduces (stream-level on RCCL); runs at the end of backward"""
+        for work, g in self._pending:
+            work.wait()
+            if g is not None:
+                g.div_(self.world_size)
+        self._pending = []
+        self._callback_queued = False
+
+    def forward(self, *args, **kwargs):
+        return self.module(*args, **kwargs)
+
+    def get_loss(self, criterion, target, preds, epoch=0):
+        return self.module.get_loss(criterion, target, preds, epoch)

@@ -1,0 +1,255 @@
+"""Temporal Binding Network with attention-weighted mid-level fusion on the MI355X HIP path.
+
+API mirror of reference core/models/model.py: `TBNModel(cfg, modality, device)` (:21-101),
+`forward(input: dict) -> OrderedDict` (:205-262), `get_loss(criterion, target, preds, epoch)`
+(:264-334), `Fusion` (:337-362), `Classifier` (:365-386); same parameter names, so reference
+checkpoints load.  Differences are implementation only: each backbone is one engine call, the
+modality features are produced by HIP pooling kernels, fusion / classifier / attention
+projections run on the fp32-MFMA GEMM, and the per-class classifiers run as ONE GEMM.
+"""
+import os
+from collections import OrderedDict
+
+import numpy as np
+import torch
+import torch.nn as nn
+from torch.distributions import Categorical
+
+from ... import ops
+from .attention import MultiheadedAttention, PositionalEncoding, PrototypeAttention, UniModalAttention
+from .bn_inception import bninception
+
+
+class _PEStack(nn.Sequential):
+    """`self.pe` of the reference (model.py:62-67): PositionalEncoding -> Conv1d(1034,1024,1) -> GroupNorm(64,1024)
+    with the reference's child names (pe.0.pe, pe.1.weight, pe.1.bias, pe.2.weight, pe.2.bias)."""
+
+    def forward_sequence(self, seq):
+        """native (R, T, 1024) -> (R, T, 1024)"""
+        conv, gn = self[1], self[2]
+        R, T, C = seq.shape
+        kin = conv.weight.shape[1]
+        kp = (kin + 31) // 32 * 32
+        x = self[0].forward_sequence(seq, kp)
+        w = torch.cat([conv.weight[:, :, 0], conv.weight.new_zeros(conv.weight.shape[0], kp - kin)], 1)
+        y = ops.linear(x.view(R * T, kp), w, conv.bias)
+        return ops.group_norm(y.view(R, T, -1), gn.weight, gn.bias, gn.num_groups, gn.eps)
+
+    def forward(self, x):
+        """reference layout (R, 1024, 1, T) -> (R, 1024, T)"""
+        return self.forward_sequence(x.squeeze(2).transpose(1, 2).contiguous()).transpose(1, 2)
+
+
+class TBNModel(nn.Module):
+    IN_CHANNELS = {"RGB": 3, "Flow": 10, "Audio": 1}
+
+    def __init__(self, cfg, modality, device, pretrained_state=None):
+        """`pretrained_state`: optional {"imagenet": sd, "kinetics": sd} replacing the `.pth` files
+        under <repo>/weights (reference model.py:122-125); None + missing files -> random init."""
+        super().__init__()
+        self.cfg = cfg
+        self.modality = modality
+        self.base_model_name = cfg.model.arch
+        self.num_classes = cfg.model.num_classes
+        self.use_attention = cfg.model.attention.enable
+        self.attention_type = cfg.model.attention.type
+        self.device = device
+        self._pretrained_state = pretrained_state
+        if cfg.model.agg_type.lower() == "avg":
+            self.agg_type = "avg"
+        else:
+            print("Incorrect aggregation type")
+            self.agg_type = None
+
+        in_features = 0
+        for m in self.modality:
+            self.add_module("Base_{}".format(m), self._create_base_model(m))
+            in_features += getattr(self, "Base_{}".format(m)).feature_size
+            if cfg.model.freeze_base:
+                self._freeze_base_model(m, freeze_mode=cfg.model.freeze_mode)
+
+        if len(self.modality) > 1:
+            att = cfg.model.attention
+            if self.use_attention and not att.use_fixed:
+                attn_win_size = round(self.cfg.data.audio.audio_length * (25 / 4))
+                if att.use_pe:
+                    self.pe = _PEStack(PositionalEncoding(10, max_len=attn_win_size, device=device),
+                                       nn.Conv1d(1034, 1024, kernel_size=1), nn.GroupNorm(64, 1024))
+                if self.attention_type == "mha":
+                    self.attention_layer = MultiheadedAttention(1024, att.attn_heads, att.attn_dropout)
+                elif self.attention_type == "unimodal":
+                    self.attention_layer = UniModalAttention(1024, attn_win_size, hidden_size=256,
+                                                             use_gumbel=att.use_gumbel, temperature=1, one_hot=True)
+                elif self.attention_type == "proto":
+                    self.attention_layer = PrototypeAttention(1024, attn_win_size, hidden_size=256,
+                                                              use_gumbel=att.use_gumbel, temperature=1, device=device)
+            self.add_module("fusion", Fusion(in_features, 512, dropout=cfg.model.fusion_dropout))
+            self.add_module("classifier", Classifier(self.num_classes, 512))
+        else:
+            self.add_module("classifier", Classifier(self.num_classes, in_features))
+
+    def _create_base_model(self, modality):
+        if self.base_model_name != "bninception":
+            raise NotImplementedError("the MI355X hot path implements the BN-Inception backbone "
+                                      f"(north star); arch '{self.base_model_name}' is out of scope")
+        pretrained = "kinetics" if modality == "Flow" else "imagenet"
+        model_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(
+            os.path.dirname(os.path.abspath(__file__))))), "weights")
+        state = None
+        if self._pretrained_state is not None:
+            state = self._pretrained_state[pretrained]
+        else:
+            fname = "kinetics_bninception_flow.pth" if pretrained == "kinetics" else "imagenet_bninception_rgb.pth"
+            if not os.path.exists(os.path.join(model_dir, fname)):
+                pretrained = None  # weights are Drive-hosted in the reference; offline -> random init
+        return bninception(self.IN_CHANNELS[modality], modality, model_dir=model_dir, pretrained=pretrained,
+                           is_audio=(modality == "Audio"), attend=self.use_attention, state_dict=state)
+
+    def _freeze_base_model(self, modality, freeze_mode):
+        base = getattr(self, "Base_{}".format(modality))
+        if freeze_mode == "all":
+            print("Freezing the Base model.")
+            for param in base.parameters():
+                param.requires_grad = False
+        elif freeze_mode == "partialbn" and self.base_model_name == "bninception":
+            print("Freezing the batchnorms of Base Model {} except first or new layers.".format(modality))
+            # reference: every BatchNorm2d child with index > 1, i.e. all but conv1_7x7_s2_bn
+            base.set_bn_trainable(first=True, rest=False)
+
+    def _aggregate_scores(self, scores, new_shape=(1, -1)):
+        assert isinstance(scores, (dict, torch.Tensor))
+        assert isinstance(new_shape, tuple)
+        b, n = new_shape[0], new_shape[1]
+        if isinstance(scores, dict):
+            for key in scores.keys():
+                scores[key] = ops.segment_mean(scores[key], b, n)
+            return scores
+        return ops.segment_mean(scores, b, n)
+
+    def forward(self, input):
+        features = []
+        att_wts = None
+        att = self.cfg.model.attention
+        for m_no, m in enumerate(self.modality):
+            b, n, c, h, w = input[m].shape
+            base_model = getattr(self, "Base_{}".format(m))
+            x = input[m].reshape(b * n, c, h, w)
+            if m == "Audio":
+                # the backbone always runs (BN running statistics advance even when the audio
+                # feature is then dropped), exactly like reference model.py:214-222
+                raw = base_model.forward_sequence(x) if self.use_attention else base_model(x)
+                if (self.training and len(self.modality) > 1 and self.cfg.data.audio.dropout > 0
+                        and np.random.uniform() > self.cfg.data.audio.dropout):
+                    feature = torch.zeros_like(features[0])
+                elif self.use_attention:
+                    seq = raw                                           # (R, T, 1024)
+                    if att.use_fixed:
+                        feature = ops.weighted_sum(seq, input["weights"].reshape(b * n, -1).to(seq.device))
+                    elif self.attention_type == "mha":
+                        seq = self.pe.forward_sequence(seq)
+                        feature, att_wts = self.attention_layer.attend(features[0], seq)
+                        att_wts = att_wts.unsqueeze(1)                  # (R, 1, T) like nn.MultiheadAttention
+                    elif self.attention_type in ["unimodal", "proto"]:
+                        feature, att_wts = self.attention_layer.attend(features[0], seq)
+                else:
+                    feature = raw
+                if m_no > 0 and features[0].shape[0] > feature.shape[0]:
+                    new_size = features[0].shape[0] // feature.shape[0]
+                    feature = feature.repeat(new_size, 1)
+                    n *= new_size
+            else:
+                feature = base_model(x)
+            features.extend([feature])
+        features = torch.cat(features, dim=1) if len(features) > 1 else features[0]
+
+        if len(self.modality) > 1:
+            features = self.fusion(features)
+
+        out = self.classifier(features, consensus=(b, n))
+
+        if self.use_attention and not att.use_fixed and len(self.modality) > 1:
+            out["weights"] = att_wts
+        return out
+
+    def get_loss(self, criterion, target, preds, epoch=0):
+        assert isinstance(target, dict)
+        assert isinstance(preds, dict)
+        assert isinstance(criterion, dict)
+        att = self.cfg.model.attention
+        loss = {"total": 0, "all_class": 0}
+        for key in target["class"].keys():
+            labels = target["class"][key]
+            batch_size = target["class"][key].shape[0]
+            loss[key] = criterion["crossentropy"](preds[key], labels)
+            loss["all_class"] += loss[key]
+        loss["total"] += loss["all_class"]
+
+        if self.use_attention and not att.use_fixed:
+            if self.training and epoch + 1 < att.decay_step:
+                prior_multiplier = contrast_multiplier = entropy_multiplier = 0
+            else:
+                prior_multiplier = att.wt_decay
+                contrast_multiplier = att.contrast_decay
+                entropy_multiplier = att.entropy_decay
+            wts = preds["weights"].squeeze(1)
+            if att.use_prior:
+                b, n, _, _ = target["weights"].shape
+                assert wts.shape[0] == b * n
+                prior = target["weights"].reshape(b * n, -1)
+                if att.wt_loss == "kl":
+                    wts = torch.log(wts + 1e-7)
+                loss["prior"] = criterion["prior"](wts, prior)
+                loss["total"] += prior_multiplier * loss["prior"]
+            if att.use_contrast:
+                loss["contrast"] = criterion["contrast"](wts)
+                loss["total"] += contrast_multiplier * loss["contrast"]
+            if att.use_entropy:
+                loss["entropy"] = Categorical(probs=wts + 1e-6).entropy().mean()
+                if self.training and entropy_multiplier > 0 and loss["entropy"] < att.entropy_thresh:
+                    entropy_multiplier = 0
+                loss["total"] += entropy_multiplier * loss["entropy"]
+        return loss, batch_size
+
+
+class Fusion(nn.Module):
+    """Linear(in, out) -> ReLU -> Dropout; the bias add and ReLU are the GEMM epilogue."""
+
+    def __init__(self, in_size, out_size, dropout=0):
+        super().__init__()
+        self.in_size, self.out_size, self.dropout = in_size, out_size, dropout
+        self.fusion_layer = nn.Sequential(nn.Linear(in_size, out_size), nn.ReLU())
+        torch.nn.init.normal_(self.fusion_layer[0].weight, 0, 1e-3)
+        torch.nn.init.constant_(self.fusion_layer[0].bias, 0)
+        if self.dropout > 0:
+            self.dropout_layer = nn.Dropout(p=self.dropout)
+
+    def forward(self, input):
+        lin = self.fusion_layer[0]
+        out = ops.linear(input, lin.weight, lin.bias, relu=True)
+        return ops.dropout(out, self.dropout, self.training)
+
+
+class Classifier(nn.Module):
+    """one nn.Linear per class key (same names as the reference) evaluated as a single GEMM"""
+
+    def __init__(self, num_classes, in_features):
+        super().__init__()
+        self.num_classes = num_classes
+        for cls in num_classes.keys():
+            self.add_module(cls, nn.Linear(in_features, self.num_classes[cls]))
+            torch.nn.init.normal_(getattr(self, cls).weight, 0, 1e-3)
+            torch.nn.init.constant_(getattr(self, cls).bias, 0)
+
+    def forward(self, input, consensus=None):
+        keys = list(self.num_classes.keys())
+        w = torch.cat([getattr(self, k).weight for k in keys], 0)
+        b = torch.cat([getattr(self, k).bias for k in keys], 0)
+        scores = ops.linear(input, w, b)
+        if consensus is not None:                       # temporal consensus on the fused score matrix
+            scores = ops.segment_mean(scores, consensus[0], consensus[1])
+        out = OrderedDict()
+        o = 0
+        for k in keys:
+            out[k] = scores[:, o:o + self.num_classes[k]]
+            o += self.num_classes[k]
+        return out

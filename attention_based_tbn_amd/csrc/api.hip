@@ -1,0 +1,226 @@
+// C-ABI glue: error reporting and the single-operator entry points of include/tbn_hip.h.
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "tbn_common.h"
+#include "tbn_kernels.h"
+#include "../../include/tbn_hip.h"
+
+static thread_local char g_err[512] = "";
+
+void tbn_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+#define TBN_TRY(expr)                \
+  do {                               \
+    int rc__ = (expr);               \
+    if (rc__ != TBN_OK) return rc__; \
+  } while (0)
+
+static void conv_geom(ConvP* p, int n, int h, int w, int cin, int cout, int k, int stride, int pad) {
+  memset(p, 0, sizeof(*p));
+  p->N = n;
+  p->H = h;
+  p->W = w;
+  p->OH = (h + 2 * pad - k) / stride + 1;
+  p->OW = (w + 2 * pad - k) / stride + 1;
+  p->Cin = cin;
+  p->Cout = cout;
+  p->R = p->S = k;
+  p->stride = stride;
+  p->pad = pad;
+  p->up = 1;
+  p->M = n * p->OH * p->OW;
+  p->K = k * k * cin;
+}
+
+extern "C" {
+
+int tbn_version(void) { return 100; }
+const char* tbn_last_error(void) { return g_err; }
+
+int tbn_conv2d_stat_tiles(int n, int h, int w, int cin, int cout, int ksize, int stride, int pad) {
+  ConvP p;
+  conv_geom(&p, n, h, w, cin, cout, ksize, stride, pad);
+  int mt, nt;
+  tbn_conv_pick_tile(p.M, p.Cout, p.K, &mt, &nt);
+  return cdiv(p.M, 128 * mt);
+}
+
+int tbn_conv2d_fwd(const float* in, int in_ld, const float* weight, const float* bias, float* out, int out_ld,
+                   int n, int h, int w, int cin, int cout, int ksize, int stride, int pad, int epilogue, int flags,
+                   const float* scale, const float* shift, float* stat_partial, void* stream) {
+  TBN_REQUIRE(in && weight && out, "conv2d_fwd: null pointer");
+  TBN_REQUIRE(epilogue >= 0 && epilogue <= 2, "conv2d_fwd: bad epilogue");
+  TBN_REQUIRE(epilogue != CONV_EPI_STATS || stat_partial, "conv2d_fwd: stats epilogue needs stat_partial");
+  TBN_REQUIRE(epilogue != CONV_EPI_EVAL || (scale && shift), "conv2d_fwd: eval epilogue needs scale/shift");
+  ConvP p;
+  conv_geom(&p, n, h, w, cin, cout, ksize, stride, pad);
+  p.in = in;
+  p.in_ld = in_ld;
+  p.wt = weight;
+  p.bias = bias;
+  p.scale = scale;
+  p.shift = shift;
+  p.stat_partial = stat_partial;
+  p.mode = epilogue;
+  p.flags = flags;
+  p.nseg = 1;
+  p.seg[0].ptr = out;
+  p.seg[0].ld = out_ld;
+  p.seg[0].col_begin = 0;
+  return tbn_launch_conv(p, 0, 0, 0, (hipStream_t)stream);
+}
+
+int tbn_conv2d_dgrad(const float* dout, int dout_ld, const float* weight, float* din, int din_ld, int n, int h, int w,
+                     int cin, int cout, int ksize, int stride, int pad, int accumulate, float* workspace,
+                     void* stream) {
+  TBN_REQUIRE(dout && weight && din && workspace, "conv2d_dgrad: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  TBN_TRY(tbn_launch_weight_flip_transpose(weight, workspace, cout, ksize * ksize, cin, st));
+  const int oh = (h + 2 * pad - ksize) / stride + 1, ow = (w + 2 * pad - ksize) / stride + 1;
+  ConvP p;
+  memset(&p, 0, sizeof(p));
+  p.in = dout;
+  p.in_ld = dout_ld;
+  p.wt = workspace;
+  p.N = n;
+  p.H = oh;
+  p.W = ow;
+  p.OH = h;
+  p.OW = w;
+  p.Cin = cout;
+  p.Cout = cin;
+  p.R = p.S = ksize;
+  p.stride = 1;
+  p.pad = ksize - 1 - pad;
+  p.up = stride;
+  p.M = n * h * w;
+  p.K = ksize * ksize * cout;
+  p.mode = CONV_EPI_PLAIN;
+  p.flags = accumulate ? CONV_FLAG_ACCUM : 0;
+  p.nseg = 1;
+  p.seg[0].ptr = din;
+  p.seg[0].ld = din_ld;
+  p.seg[0].col_begin = 0;
+  return tbn_launch_conv(p, 0, 0, 0, st);
+}
+
+static void wgrad_geom(WgradP* wp, int n, int h, int w, int cin, int cout, int k, int stride, int pad) {
+  memset(wp, 0, sizeof(*wp));
+  wp->N = n;
+  wp->H = h;
+  wp->W = w;
+  wp->OH = (h + 2 * pad - k) / stride + 1;
+  wp->OW = (w + 2 * pad - k) / stride + 1;
+  wp->Cin = cin;
+  wp->Cout = cout;
+  wp->R = wp->S = k;
+  wp->taps = k * k;
+  wp->stride = stride;
+  wp->pad = pad;
+  wp->M = n * wp->OH * wp->OW;
+}
+
+size_t tbn_conv2d_wgrad_workspace_floats(int n, int h, int w, int cin, int cout, int ksize, int stride, int pad) {
+  WgradP wp;
+  wgrad_geom(&wp, n, h, w, cin, cout, ksize, stride, pad);
+  return tbn_wgrad_workspace_floats(wp.M, cout, cin, ksize * ksize);
+}
+
+int tbn_conv2d_wgrad(const float* dout, int dout_ld, const float* in, int in_ld, float* dweight, int n, int h, int w,
+                     int cin, int cout, int ksize, int stride, int pad, float* workspace, void* stream) {
+  TBN_REQUIRE(dout && in && dweight, "conv2d_wgrad: null pointer");
+  WgradP wp;
+  wgrad_geom(&wp, n, h, w, cin, cout, ksize, stride, pad);
+  wp.dy = dout;
+  wp.dy_ld = dout_ld;
+  wp.x = in;
+  wp.x_ld = in_ld;
+  return tbn_launch_wgrad(wp, 0, dweight, workspace, (hipStream_t)stream);
+}
+
+// ---- linear = 1x1 conv over an (m,1,1,k) "image"
+int tbn_linear_fwd(const float* x, int x_ld, const float* w, const float* bias, float* out, int out_ld, int m, int k,
+                   int n, int relu, void* stream) {
+  return tbn_conv2d_fwd(x, x_ld, w, bias, out, out_ld, m, 1, 1, k, n, 1, 1, 0, CONV_EPI_PLAIN,
+                        relu ? CONV_FLAG_RELU : 0, nullptr, nullptr, nullptr, stream);
+}
+
+int tbn_linear_dgrad(const float* dy, int dy_ld, const float* w, float* dx, int dx_ld, int m, int k, int n,
+                     int accumulate, float* workspace, void* stream) {
+  return tbn_conv2d_dgrad(dy, dy_ld, w, dx, dx_ld, m, 1, 1, k, n, 1, 1, 0, accumulate, workspace, stream);
+}
+
+size_t tbn_linear_wgrad_workspace_floats(int m, int k, int n) { return tbn_wgrad_workspace_floats(m, n, k, 1); }
+
+int tbn_linear_wgrad(const float* dy, int dy_ld, const float* x, int x_ld, float* dw, float* dbias, int m, int k,
+                     int n, float* workspace, void* stream) {
+  TBN_TRY(tbn_conv2d_wgrad(dy, dy_ld, x, x_ld, dw, m, 1, 1, k, n, 1, 1, 0, workspace, stream));
+  if (dbias) TBN_TRY(tbn_colsum(dy, dy_ld, dbias, m, n, stream));
+  return TBN_OK;
+}
+
+// ---- standalone training BN + ReLU
+size_t tbn_bn_workspace_floats(int p, int c) { return (size_t)tbn_bn_stats_parts(p, c) * 2 * c + 3 * (size_t)c; }
+
+int tbn_bn_relu_train_fwd(const float* y, int p, int c, const float* gamma, const float* beta, float* running_mean,
+                          float* running_var, float momentum, float eps, float* save_mean, float* save_rstd,
+                          float* scale, float* shift, float* z, int z_ld, float* workspace, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  int parts = 0;
+  TBN_TRY(tbn_launch_bn_stats(y, c, p, c, workspace, &parts, st));
+  TBN_TRY(tbn_launch_bn_finalize(workspace, parts, p, c, gamma, beta, running_mean, running_var, momentum, eps,
+                                 save_mean, save_rstd, scale, shift, st));
+  Seg s;
+  s.ptr = z;
+  s.ld = z_ld;
+  s.col_begin = 0;
+  return tbn_launch_bn_apply(y, p, c, scale, shift, &s, 1, st);
+}
+
+int tbn_bn_relu_train_bwd(const float* dz, int dz_ld, const float* y, int p, int c, const float* save_mean,
+                          const float* save_rstd, const float* scale, const float* shift, float* dy, float* dgamma,
+                          float* dbeta, float* workspace, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  CSeg s;
+  s.ptr = dz;
+  s.ld = dz_ld;
+  s.col_begin = 0;
+  const int parts = tbn_bn_bwd_parts(p, c);
+  float* coef = workspace + (size_t)parts * 2 * c;
+  TBN_TRY(tbn_launch_bn_bwd_reduce(&s, 1, y, p, c, scale, shift, save_mean, save_rstd, workspace, st));
+  TBN_TRY(tbn_launch_bn_bwd_finalize(workspace, parts, p, c, scale, save_mean, save_rstd, coef, dgamma, dbeta, nullptr,
+                                     st));
+  return tbn_launch_bn_bwd_apply(&s, 1, y, p, c, scale, shift, coef, dy, st);
+}
+
+// ---- pooling
+int tbn_maxpool3_fwd(const float* in, int in_ld, float* out, int out_ld, uint8_t* argmax, int n, int h, int w, int c,
+                     int oh, int ow, int stride, int pad, void* stream) {
+  return tbn_launch_maxpool_fwd(in, in_ld, out, out_ld, argmax, n, h, w, c, oh, ow, stride, pad, (hipStream_t)stream);
+}
+int tbn_maxpool3_bwd(const float* dout, int dout_ld, const uint8_t* argmax, float* din, int din_ld, int n, int h,
+                     int w, int c, int oh, int ow, int stride, int pad, int accumulate, void* stream) {
+  return tbn_launch_maxpool_bwd(dout, dout_ld, argmax, din, din_ld, n, h, w, c, oh, ow, stride, pad, accumulate,
+                                (hipStream_t)stream);
+}
+int tbn_avgpool3_fwd(const float* in, int in_ld, float* out, int out_ld, int n, int h, int w, int c, int accumulate,
+                     void* stream) {
+  return tbn_launch_avgpool3_fwd(in, in_ld, out, out_ld, n, h, w, c, accumulate, (hipStream_t)stream);
+}
+int tbn_spatial_mean_fwd(const float* in, int in_ld, float* out, int out_ld, int n, int h, int w, int c,
+                         int freq_only, void* stream) {
+  return tbn_launch_spatial_mean_fwd(in, in_ld, out, out_ld, n, h, w, c, freq_only, (hipStream_t)stream);
+}
+int tbn_spatial_mean_bwd(const float* dout, int dout_ld, float* din, int din_ld, int n, int h, int w, int c,
+                         int freq_only, void* stream) {
+  return tbn_launch_spatial_mean_bwd(dout, dout_ld, din, din_ld, n, h, w, c, freq_only, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,546 @@
+// Implicit-GEMM 2-D convolution for gfx950 on the fp32 MFMA (v_mfma_f32_32x32x2_f32).
+//
+// Replaces, for the TBN hot path, what the reference gets from cuDNN through nn.Conv2d
+// (graph: reference core/models/bn_inception_audio.py:24-401; 7x7 stem bn_inception.py:75-77).
+//
+// Data layout (MI355X-first, not the reference's NCHW):
+//   activations NHWC fp32 with an explicit row pitch `ld` so a conv can read / write a channel
+//   slice of a wider concat buffer; weights [Cout][R][S][Cin] (= torch channels_last memory of the
+//   OIHW parameter), i.e. GEMM-B rows are K-contiguous.
+// GEMM view:  M = N*OH*OW output pixels, N = Cout, K = R*S*Cin.
+//   A (pixels x K) is gathered on the fly (im2col never materialised), staged through LDS in
+//   [row][32+4] fp32 tiles: 128-B coalesced global reads per 8 lanes, ds_write_b128, and
+//   conflict-free ds_read_b128 fragments (k is permuted identically for A and B, so one b128
+//   read feeds 4 MFMAs).  4 waves per workgroup stacked along M, each owning (32*MT) x (32*NT).
+//   blockIdx -> tile mapping is XCD-aware: the 8 tiles that share an activation row-panel
+//   sit on one XCD so the panel is fetched into one L2 only.
+// Epilogues (runtime switch): plain(+bias,+relu,+accumulate) | raw+bias with fused per-channel
+//   sum / sum-of-squares partials for training-mode BatchNorm | eval BN folded scale/shift + ReLU.
+// The same kernel is the data-gradient: dgrad = conv of dy with tap-flipped, channel-transposed
+//   weights (`up` = forward stride handles strided layers by zero-insertion on the fly).
+// ROWMODE is the 7x7 stem: input is NHWC padded to `cp` channels, a filter row (7*cp floats,
+//   padded to a multiple of 32) is one contiguous K run.
+#include "tbn_common.h"
+#include "tbn_kernels.h"
+
+#define LDT 36  // LDS row pitch in floats (32 + 4): 16-B aligned rows, conflict-free b128 reads
+
+template <int MT, int NT, bool ROWMODE>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
+  constexpr int BM = 128 * MT, BN = 32 * NT;
+  constexpr int AR = 4 * MT;  // A rows per thread
+  __shared__ __attribute__((aligned(16))) float lds[(BM + BN) * LDT];
+  float* As = lds;
+  float* Bs = lds + BM * LDT;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // XCD-aware bijective remap: blocks b, b+8, ... share an XCD -> give them consecutive tiles
+  const int nb = p.tiles_m * p.tiles_n;
+  const int bid = blockIdx.x;
+  const int q8 = nb >> 3, r8 = nb & 7, xcd = bid & 7, idx = bid >> 3;
+  const int nid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+  const int tm = nid / p.tiles_n, tn = nid - tm * p.tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const int c4 = tid & 7, r0 = tid >> 3;
+  int a_base[AR];  // pixel index of (n,0,0), or -1 when the output row is out of range
+  int a_yx[AR];    // packed (iy0 << 16) | (ix0 & 0xffff)
+  {
+    const int ohw = p.OH * p.OW;
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+      const int m = m0 + r0 + 32 * i;
+      if (m < p.M) {
+        const int n = m / ohw, rem = m - n * ohw;
+        const int oy = rem / p.OW, ox = rem - oy * p.OW;
+        a_base[i] = n * p.H * p.W;
+        a_yx[i] = ((oy * p.stride - p.pad) << 16) | ((ox * p.stride - p.pad) & 0xffff);
+      } else {
+        a_base[i] = -1;
+        a_yx[i] = 0;
+      }
+    }
+  }
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int cps = p.Cin >> 5;  // 32-float chunks per tap
+  const int ksteps = p.K >> 5;
+  float4 ra[AR], rb[NT];
+
+  auto load_tiles = [&](int ks) {
+    const int tap = ks / cps;
+    const int c0 = (ks - tap * cps) << 5;
+    int r, s;
+    if (ROWMODE) {
+      r = tap;
+      s = 0;
+    } else {
+      r = tap / p.S;
+      s = tap - r * p.S;
+    }
+    const int cc = c0 + c4 * 4;
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (a_base[i] >= 0) {
+        int iy = (a_yx[i] >> 16) + r;
+        int ix = (int)(short)(a_yx[i] & 0xffff) + s;
+        bool ok = true;
+        if (p.up > 1) {  // data-gradient of a strided conv: only every `up`-th position exists
+          ok = (iy >= 0) && (ix >= 0) && ((iy % p.up) == 0) && ((ix % p.up) == 0);
+          iy /= p.up;
+          ix /= p.up;
+        }
+        if (!ROWMODE) {
+          ok = ok && ((unsigned)iy < (unsigned)p.H) && ((unsigned)ix < (unsigned)p.W);
+          if (ok) v = *reinterpret_cast<const float4*>(p.in + (size_t)(a_base[i] + iy * p.W + ix) * p.in_ld + cc);
+        } else {
+          const int px = ix + cc / p.cp;
+          ok = ((unsigned)iy < (unsigned)p.H) && ((unsigned)px < (unsigned)p.W);
+          if (ok)
+            v = *reinterpret_cast<const float4*>(p.in + (ptrdiff_t)(a_base[i] + iy * p.W) * p.cp +
+                                                 ((ptrdiff_t)ix * p.cp + cc));
+        }
+      }
+      ra[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      const int co = n0 + r0 + 32 * i;
+      rb[i] = (co < p.Cout) ? *reinterpret_cast<const float4*>(p.wt + (size_t)co * p.K + (ks << 5) + c4 * 4)
+                            : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto store_tiles = [&]() {
+#pragma unroll
+    for (int i = 0; i < AR; ++i) *reinterpret_cast<float4*>(&As[(r0 + 32 * i) * LDT + c4 * 4]) = ra[i];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) *reinterpret_cast<float4*>(&Bs[(r0 + 32 * i) * LDT + c4 * 4]) = rb[i];
+  };
+
+  load_tiles(0);
+  store_tiles();
+  __syncthreads();
+
+  const int lrow = lane & 31, lhalf = lane >> 5;
+  for (int ks = 0; ks < ksteps; ++ks) {
+    const bool more = (ks + 1 < ksteps);
+    if (more) load_tiles(ks + 1);  // global loads stay in flight under the MFMA phase
+#pragma unroll
+    for (int kg = 0; kg < 4; ++kg) {
+      float4 a[MT], b[NT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+        a[i] = *reinterpret_cast<const float4*>(&As[(wave * 32 * MT + i * 32 + lrow) * LDT + kg * 8 + lhalf * 4]);
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+        b[j] = *reinterpret_cast<const float4*>(&Bs[(j * 32 + lrow) * LDT + kg * 8 + lhalf * 4]);
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          if (n0 + j * 32 < p.Cout) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+          }
+        }
+    }
+    __syncthreads();
+    if (more) {
+      store_tiles();
+      __syncthreads();
+    }
+  }
+
+  // ---------------------------------------------------------------- epilogue
+  float* red = lds;  // [2][4 waves][BN] for the BN-statistics partials (tiles are dead now)
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int colb = n0 + j * 32;
+    if (colb >= p.Cout) continue;  // block-uniform
+    const int col = colb + lrow;
+    const bool col_ok = col < p.Cout;
+    int sg = 0;
+    if (p.nseg > 1 && colb >= p.seg[1].col_begin) sg = 1;
+    if (p.nseg > 2 && colb >= p.seg[2].col_begin) sg = 2;
+    float* obase = p.seg[sg].ptr + (col - p.seg[sg].col_begin);
+    const int old = p.seg[sg].ld;
+    const float bias = (p.bias != nullptr && col_ok) ? p.bias[col] : 0.f;
+    float sc = 1.f, sh = 0.f;
+    if (p.mode == CONV_EPI_EVAL && col_ok) {
+      sc = p.scale[col];
+      sh = p.shift[col];
+    }
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = m0 + wave * 32 * MT + i * 32 + 8 * (e >> 2) + 4 * lhalf + (e & 3);
+        float v = acc[i][j][e] + bias;
+        if (m < p.M && col_ok) {
+          float* o = obase + (size_t)m * old;
+          if (p.mode == CONV_EPI_EVAL) {
+            v = fmaxf(fmaf(v, sc, sh), 0.f);
+          } else if (p.mode == CONV_EPI_STATS) {
+            s1 += v;
+            s2 = fmaf(v, v, s2);
+          } else {
+            if (p.flags & CONV_FLAG_ACCUM) v += *o;
+            if (p.flags & CONV_FLAG_RELU) v = fmaxf(v, 0.f);
+          }
+          *o = v;
+        }
+      }
+    }
+    if (p.mode == CONV_EPI_STATS) {
+      s1 += __shfl_xor(s1, 32);
+      s2 += __shfl_xor(s2, 32);
+      if (lhalf == 0) {
+        red[(0 * 4 + wave) * BN + j * 32 + lrow] = s1;
+        red[(1 * 4 + wave) * BN + j * 32 + lrow] = s2;
+      }
+    }
+  }
+  if (p.mode == CONV_EPI_STATS) {
+    __syncthreads();
+    if (tid < BN && n0 + tid < p.Cout) {
+      float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        t1 += red[(0 * 4 + w) * BN + tid];
+        t2 += red[(1 * 4 + w) * BN + tid];
+      }
+      p.stat_partial[((size_t)tm * 2 + 0) * p.Cout + n0 + tid] = t1;
+      p.stat_partial[((size_t)tm * 2 + 1) * p.Cout + n0 + tid] = t2;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Weight gradient:  dW[co][tap][ci] = sum_m dy[m][co] * x[pix(m) + tap][ci]
+// GEMM with the *pixel* index as the reduction dim.  Both operands are read as K-major rows
+// (pixel rows, channel-contiguous) and used straight from a [k][32*T+4] LDS tile with
+// ds_read_b32 fragments (lane -> (k = lane>>5, i = lane&31) is conflict-free).  Each of the 4
+// waves of a workgroup reduces a different quarter of the workgroup's pixel range over the same
+// (32*MT co) x (32*NT ci) tile of one filter tap; the 4 partial tiles are summed through LDS
+// in fixed order (deterministic), then stored to `out` (final dW or a split-K slab).
+template <int MT, int NT, bool ROWMODE>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
+  constexpr int WA = 32 * MT + 4, WB = 32 * NT + 4;  // LDS pitches
+  constexpr int KR = 16;                             // pixel rows per wave step
+  constexpr int TILE = KR * (WA + WB);
+  constexpr int LDSF = (4 * TILE > 4 * 1024 ? 4 * TILE : 4 * 1024);
+  __shared__ __attribute__((aligned(16))) float lds[LDSF];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* At = lds + wave * TILE;
+  float* Bt = At + KR * WA;
+
+  // block -> (split, tap, tile_ci, tile_co); co fastest so neighbours share the x rows in L2
+  int b = blockIdx.x;
+  const int tco = b % p.tiles_co;
+  b /= p.tiles_co;
+  const int tci = b % p.tiles_ci;
+  b /= p.tiles_ci;
+  const int tap = b % p.taps;
+  const int split = b / p.taps;
+  const int co0 = tco * 32 * MT, ci0 = tci * 32 * NT;
+  int r, s;
+  if (ROWMODE) {
+    r = tap;
+    s = 0;
+  } else {
+    r = tap / p.S;
+    s = tap - r * p.S;
+  }
+  const int pbeg = split * p.rows_per_split;
+  const int pend = min(p.M, pbeg + p.rows_per_split);
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  constexpr int AF = KR * 8 * MT, BF = KR * 8 * NT;  // float4 items per tile
+  constexpr int AI = (AF + 63) / 64, BI = (BF + 63) / 64;
+  float4 ra[AI], rb[BI];
+
+  auto load_tiles = [&](int row0) {
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      const int f = lane + 64 * i;
+      const int row = f / (8 * MT), c = (f - row * (8 * MT)) * 4;
+      const int m = row0 + row;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (f < AF && m < pend && co0 + c < p.Cout)
+        v = *reinterpret_cast<const float4*>(p.dy + (size_t)m * p.dy_ld + co0 + c);
+      ra[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+      const int f = lane + 64 * i;
+      const int row = f / (8 * NT), c = (f - row * (8 * NT)) * 4;
+      const int m = row0 + row;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (f < BF && m < pend && ci0 + c < p.Cin) {
+        const uint32_t n = fdiv((uint32_t)m, p.div_ohw);
+        const uint32_t rem = (uint32_t)m - n * p.div_ohw.d;
+        const uint32_t oy = fdiv(rem, p.div_ow);
+        const uint32_t ox = rem - oy * p.div_ow.d;
+        const int iy = (int)oy * p.stride - p.pad + r;
+        const int ix = (int)ox * p.stride - p.pad + s;
+        const int cc = ci0 + c;
+        if (!ROWMODE) {
+          if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+            v = *reinterpret_cast<const float4*>(p.x + (size_t)((n * p.H + iy) * p.W + ix) * p.x_ld + cc);
+        } else {
+          const int px = ix + cc / p.cp;
+          if ((unsigned)iy < (unsigned)p.H && (unsigned)px < (unsigned)p.W)
+            v = *reinterpret_cast<const float4*>(p.x + (ptrdiff_t)((n * p.H + iy) * p.W) * p.cp +
+                                                 ((ptrdiff_t)ix * p.cp + cc));
+        }
+      }
+      rb[i] = v;
+    }
+  };
+  auto store_tiles = [&]() {
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      const int f = lane + 64 * i;
+      const int row = f / (8 * MT), c = (f - row * (8 * MT)) * 4;
+      if (f < AF) *reinterpret_cast<float4*>(&At[row * WA + c]) = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+      const int f = lane + 64 * i;
+      const int row = f / (8 * NT), c = (f - row * (8 * NT)) * 4;
+      if (f < BF) *reinterpret_cast<float4*>(&Bt[row * WB + c]) = rb[i];
+    }
+  };
+
+  // every wave runs the same trip count (rows beyond pend load zeros) so barriers line up
+  const int nsteps = (p.rows_per_split + 4 * KR - 1) / (4 * KR);
+  const int lrow = lane & 31, lhalf = lane >> 5;
+  load_tiles(pbeg + wave * KR);
+  for (int it = 0; it < nsteps; ++it) {
+    store_tiles();
+    __syncthreads();
+    if (it + 1 < nsteps) load_tiles(pbeg + ((it + 1) * 4 + wave) * KR);
+#pragma unroll
+    for (int kp = 0; kp < KR / 2; ++kp) {
+      float a[MT], bb[NT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) a[i] = At[(2 * kp + lhalf) * WA + i * 32 + lrow];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) bb[j] = Bt[(2 * kp + lhalf) * WB + j * 32 + lrow];
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bb[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  // cross-wave reduction, one 32x32 sub-tile at a time: red[wave][32*32]
+  float* red = lds;
+  float* obase = p.out + (size_t)split * p.Cout * p.K;
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = 8 * (e >> 2) + 4 * lhalf + (e & 3);
+        red[wave * 1024 + row * 32 + lrow] = acc[i][j][e];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int el = tid + 256 * t;
+        const float v = (red[el] + red[1024 + el]) + (red[2048 + el] + red[3072 + el]);
+        const int row = el >> 5, col = el & 31;
+        const int co = co0 + i * 32 + row, ci = ci0 + j * 32 + col;
+        if (co < p.Cout && ci < p.Cin) obase[(size_t)co * p.K + tap * p.Cin + ci] = v;
+      }
+      __syncthreads();
+    }
+}
+
+__global__ void splitk_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int n4, int splits,
+                                     size_t slab4) {
+  const float4* p4 = reinterpret_cast<const float4*>(part);
+  float4* o4 = reinterpret_cast<float4*>(out);
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += gridDim.x * blockDim.x) {
+    float4 a = p4[i];
+    for (int s = 1; s < splits; ++s) {
+      const float4 v = p4[(size_t)s * slab4 + i];
+      a.x += v.x;
+      a.y += v.y;
+      a.z += v.z;
+      a.w += v.w;
+    }
+    o4[i] = a;
+  }
+}
+
+// Wt[ci][T-1-tap][co] = W[co][tap][ci]  (tap-flipped, channel-transposed weights for dgrad)
+__global__ void weight_flip_transpose_kernel(const float* __restrict__ w, float* __restrict__ wt, int Cout, int taps,
+                                             int Cin) {
+  __shared__ float tile[32][33];
+  const int tap = blockIdx.z;
+  const int co0 = blockIdx.y * 32, ci0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: 32 x 8
+  for (int i = ty; i < 32; i += 8) {
+    const int co = co0 + i, ci = ci0 + tx;
+    tile[i][tx] = (co < Cout && ci < Cin) ? w[((size_t)co * taps + tap) * Cin + ci] : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int ci = ci0 + i, co = co0 + tx;
+    if (ci < Cin && co < Cout) wt[((size_t)ci * taps + (taps - 1 - tap)) * Cout + co] = tile[tx][i];
+  }
+}
+
+// ------------------------------------------------------------------------------------------ host
+template <int MT, int NT, bool RM>
+static void launch_conv(const ConvP& p, hipStream_t st) {
+  hipLaunchKernelGGL((conv_igemm_kernel<MT, NT, RM>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, st, p);
+}
+
+void tbn_conv_pick_tile(int M, int Cout, int K, int* mt_out, int* nt_out) {
+  double best = 1e300;
+  int bm = 1, bn = 1;
+  for (int mt = 1; mt <= 2; ++mt)
+    for (int nt = 1; nt <= 4; ++nt) {
+      const int tiles_m = cdiv(M, 128 * mt), tiles_n = cdiv(Cout, 32 * nt);
+      const double blocks = (double)tiles_m * tiles_n;
+      const double rounds = (double)((long)((blocks + 255) / 256));
+      // MFMA cycles per k-step per wave + fixed per-step (barriers, exposed latency) + per-block cost
+      const double per_block = (K / 32.0) * (mt * nt * 1024.0 + 350.0) + 4000.0;
+      // wasted columns in the last N tile still cost load/issue slots but no MFMA (skipped)
+      double cost = rounds * per_block;
+      // prefer bigger tiles on ties (less L2 traffic)
+      cost *= 1.0 + 0.01 / (mt * nt);
+      if (cost < best) {
+        best = cost;
+        bm = mt;
+        bn = nt;
+      }
+    }
+  *mt_out = bm;
+  *nt_out = bn;
+}
+
+int tbn_launch_conv(ConvP p, int rowmode, int mt, int nt, hipStream_t st) {
+  TBN_REQUIRE(p.K % 32 == 0 && p.Cin % 32 == 0, "conv: K (%d) and per-tap Cin (%d) must be multiples of 32", p.K,
+              p.Cin);
+  TBN_REQUIRE(p.in_ld % 4 == 0 && p.nseg >= 1 && p.nseg <= 3, "conv: bad in_ld %d / nseg %d", p.in_ld, p.nseg);
+  TBN_REQUIRE(p.up == 1 || p.up == 2, "conv: up must be 1 or 2");
+  TBN_REQUIRE(p.M > 0 && (long)p.N * p.H * p.W < (1l << 31), "conv: pixel count out of range");
+  if (mt <= 0 || nt <= 0) tbn_conv_pick_tile(p.M, p.Cout, p.K, &mt, &nt);
+  p.tiles_m = cdiv(p.M, 128 * mt);
+  p.tiles_n = cdiv(p.Cout, 32 * nt);
+#define TBN_CASE(MTv, NTv)                                     \
+  if (mt == MTv && nt == NTv) {                                \
+    if (rowmode)                                               \
+      launch_conv<MTv, NTv, true>(p, st);                      \
+    else                                                       \
+      launch_conv<MTv, NTv, false>(p, st);                     \
+  } else
+  TBN_CASE(1, 1) TBN_CASE(1, 2) TBN_CASE(1, 3) TBN_CASE(1, 4) TBN_CASE(2, 1) TBN_CASE(2, 2) TBN_CASE(2, 3)
+  TBN_CASE(2, 4) {
+    tbn_set_error("conv: unsupported tile %dx%d", mt, nt);
+    return TBN_ERR_UNSUPPORTED;
+  }
+#undef TBN_CASE
+  TBN_CHECK_LAUNCH("conv_igemm");
+  return TBN_OK;
+}
+
+template <int MT, int NT, bool RM>
+static void launch_wgrad(const WgradP& p, int blocks, hipStream_t st) {
+  hipLaunchKernelGGL((conv_wgrad_kernel<MT, NT, RM>), dim3(blocks), dim3(256), 0, st, p);
+}
+
+static int pick_wtile(int c) { return (c % 64 == 0 || c > 96) ? 2 : 1; }
+
+// plan: tile + split-K so that the grid has >= ~3 workgroups per CU and every split >= 256 rows
+void tbn_wgrad_plan(int M, int Cout, int Cin, int taps, int* mt, int* nt, int* splits, int* rows_per_split) {
+  *mt = pick_wtile(Cout);
+  *nt = pick_wtile(Cin);
+  const int tiles = cdiv(Cout, 32 * *mt) * cdiv(Cin, 32 * *nt) * taps;
+  int want = cdiv(768, tiles);
+  int max_splits = cdiv(M, 256);
+  int s = want < 1 ? 1 : want;
+  if (s > max_splits) s = max_splits;
+  if (s < 1) s = 1;
+  int rps = cdiv(cdiv(M, s), 64) * 64;
+  s = cdiv(M, rps);
+  *splits = s;
+  *rows_per_split = rps;
+}
+
+size_t tbn_wgrad_workspace_floats(int M, int Cout, int Cin, int taps) {
+  int mt, nt, s, rps;
+  tbn_wgrad_plan(M, Cout, Cin, taps, &mt, &nt, &s, &rps);
+  return s > 1 ? (size_t)s * Cout * taps * Cin : 0;
+}
+
+int tbn_launch_wgrad(WgradP p, int rowmode, float* dw, float* workspace, hipStream_t st) {
+  TBN_REQUIRE(p.Cin % 4 == 0 && p.Cout % 4 == 0 && p.dy_ld % 4 == 0 && p.x_ld % 4 == 0,
+              "wgrad: channel counts / pitches must be multiples of 4");
+  TBN_REQUIRE((long)p.N * p.H * p.W < (1l << 31) && p.M > 0, "wgrad: pixel count out of range");
+  int mt, nt, splits, rps;
+  tbn_wgrad_plan(p.M, p.Cout, p.Cin, p.taps, &mt, &nt, &splits, &rps);
+  p.K = p.taps * p.Cin;
+  p.tiles_co = cdiv(p.Cout, 32 * mt);
+  p.tiles_ci = cdiv(p.Cin, 32 * nt);
+  p.rows_per_split = rps;
+  p.div_ohw = make_fastdiv((uint32_t)(p.OH * p.OW));
+  p.div_ow = make_fastdiv((uint32_t)p.OW);
+  TBN_REQUIRE(splits == 1 || workspace != nullptr, "wgrad: split-K needs a workspace");
+  p.out = splits > 1 ? workspace : dw;
+  const int blocks = p.tiles_co * p.tiles_ci * p.taps * splits;
+#define TBN_CASE(MTv, NTv)                                          \
+  if (mt == MTv && nt == NTv) {                                     \
+    if (rowmode)                                                    \
+      launch_wgrad<MTv, NTv, true>(p, blocks, st);                  \
+    else                                                            \
+      launch_wgrad<MTv, NTv, false>(p, blocks, st);                 \
+  } else
+  TBN_CASE(1, 1) TBN_CASE(1, 2) TBN_CASE(2, 1) TBN_CASE(2, 2) {
+    tbn_set_error("wgrad: unsupported tile");
+    return TBN_ERR_UNSUPPORTED;
+  }
+#undef TBN_CASE
+  TBN_CHECK_LAUNCH("conv_wgrad");
+  if (splits > 1) {
+    const size_t n = (size_t)p.Cout * p.K;
+    const int n4 = (int)(n / 4);
+    int grid = cdiv(n4, 256);
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, st, workspace, dw, n4, splits, n / 4);
+    TBN_CHECK_LAUNCH("splitk_reduce");
+  }
+  return TBN_OK;
+}
+
+int tbn_launch_weight_flip_transpose(const float* w, float* wt, int Cout, int taps, int Cin, hipStream_t st) {
+  hipLaunchKernelGGL(weight_flip_transpose_kernel, dim3(cdiv(Cin, 32), cdiv(Cout, 32), taps), dim3(256), 0, st, w,
+                     wt, Cout, taps, Cin);
+  TBN_CHECK_LAUNCH("weight_flip_transpose");
+  return TBN_OK;
+}

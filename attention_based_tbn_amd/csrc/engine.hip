@@ -1,0 +1,636 @@
+// BN-Inception backbone engine: the whole per-modality conv stack as one natively scheduled
+// program of HIP launches on one stream (forward train / forward eval / backward).
+//
+// Graph: reference core/models/bn_inception_audio.py:58-404 (layers) and :437-1003 (dataflow, concat
+// order 1x1 | 3x3 | double-3x3 | pool) with the 7x7 stem of core/models/bn_inception.py:75-77.
+// MI355X-first choices (vs. the reference's one nn.Module call per layer):
+//   * NHWC activations; every branch writes straight into its channel slice of the block's
+//     concat buffer (no torch.cat copies);
+//   * the 1x1 convs that read the same block input (1x1, 3x3_reduce, double_3x3_reduce) run as ONE
+//     GEMM (their parameters are adjacent in the flat parameter arrays), forward and backward;
+//   * training-mode BatchNorm statistics are produced by the conv epilogue (no extra pass over y);
+//   * all parameters of a backbone live in 6 flat arrays, gradients likewise -> the data-parallel
+//     all-reduce and the optimizer touch a handful of large tensors (RCCL/xGMI friendly);
+//   * the caller owns all memory: one workspace blob sized by tbn_backbone_workspace_bytes().
+#include <string>
+#include <vector>
+#include <cstring>
+#include <cstdio>
+
+#include "tbn_common.h"
+#include "tbn_kernels.h"
+#include "../../include/tbn_hip.h"
+
+namespace {
+
+struct BlockSpec {
+  const char* name;
+  int cin, c1, c3r, c3, cdr, cd1, cd2;
+  int pool;  // 0 avg->proj, 1 max(s1)->proj, 2 max(s2) pass-through
+  int cp, stride;
+};
+const BlockSpec kBlocks[] = {
+    {"3a", 192, 64, 64, 64, 64, 96, 96, 0, 32, 1},     {"3b", 256, 64, 64, 96, 64, 96, 96, 0, 64, 1},
+    {"3c", 320, 0, 128, 160, 64, 96, 96, 2, 0, 2},     {"4a", 576, 224, 64, 96, 96, 128, 128, 0, 128, 1},
+    {"4b", 576, 192, 96, 128, 96, 128, 128, 0, 128, 1}, {"4c", 576, 160, 128, 160, 128, 160, 160, 0, 128, 1},
+    {"4d", 608, 96, 128, 192, 160, 192, 192, 0, 128, 1}, {"4e", 608, 0, 128, 192, 192, 256, 256, 2, 0, 2},
+    {"5a", 1056, 352, 192, 320, 160, 224, 224, 0, 128, 1}, {"5b", 1024, 352, 192, 320, 192, 224, 224, 1, 128, 1},
+};
+const int kNumBlocks = 10;
+
+struct Buf {
+  int H, W, C;
+  size_t off, doff;  // float offsets of z and dz in the workspace
+};
+
+struct Conv {
+  int nparts;
+  std::string names[3];
+  int couts[3];
+  int cin, cout, k, stride, pad;
+  int inbuf, inH, inW, outH, outW;
+  int dst_buf[3], dst_choff[3];
+  size_t w_off, c_off;
+  size_t y_off;
+  int mt, nt;          // forward tile
+  int d_mt, d_nt;      // dgrad tile
+  bool stem;
+  bool dgrad_accum;    // dgrad adds into d(inbuf)
+  bool need_dgrad;
+};
+
+struct Pool {
+  int kind;  // 0 avg3, 1 max
+  int inbuf, outbuf, out_choff, stride, pad;
+  size_t argmax_off;   // bytes
+  bool bwd_accum;
+};
+
+struct Op {
+  int kind;  // 0 conv, 1 pool
+  int idx;
+};
+
+int pool_out(int in, int k, int stride, int pad, bool ceil_mode) {
+  int num = in + 2 * pad - k;
+  int o = (ceil_mode ? (num + stride - 1) / stride : num / stride) + 1;
+  if (ceil_mode && (o - 1) * stride >= in + pad) --o;
+  return o;
+}
+
+}  // namespace
+
+struct tbn_backbone_plan {
+  int cin0, frames, H, W;
+  int cp, kw;  // stem channel padding / padded filter-row length
+  std::vector<Buf> bufs;
+  std::vector<Conv> convs;
+  std::vector<Pool> pools;
+  std::vector<Op> ops;
+  int out_buf;
+  size_t weight_floats, chan_floats;
+  // workspace layout (float offsets unless noted)
+  size_t x0_off, stats_off, partial_off, coef_off, wsplit_off, wt_off, wpack_off, dwpack_off;
+  size_t partial_floats, wsplit_floats, wt_floats;
+  size_t argmax_bytes_off, total_bytes_train, total_bytes_eval;
+  size_t eval_floats;
+};
+
+namespace {
+
+int add_buf(tbn_backbone_plan* P, int H, int W, int C) {
+  Buf b;
+  b.H = H;
+  b.W = W;
+  b.C = C;
+  b.off = b.doff = 0;
+  P->bufs.push_back(b);
+  return (int)P->bufs.size() - 1;
+}
+
+int add_conv(tbn_backbone_plan* P, int nparts, const std::string* names, const int* couts, int cin, int k, int stride,
+             int pad, int inbuf, const int* dst_buf, const int* dst_choff, bool stem) {
+  Conv c;
+  c.nparts = nparts;
+  c.cout = 0;
+  for (int i = 0; i < nparts; ++i) {
+    c.names[i] = names[i];
+    c.couts[i] = couts[i];
+    c.dst_buf[i] = dst_buf[i];
+    c.dst_choff[i] = dst_choff[i];
+    c.cout += couts[i];
+  }
+  c.cin = cin;
+  c.k = k;
+  c.stride = stride;
+  c.pad = pad;
+  c.inbuf = inbuf;
+  c.inH = P->bufs[inbuf].H;
+  c.inW = P->bufs[inbuf].W;
+  c.outH = (c.inH + 2 * pad - k) / stride + 1;
+  c.outW = (c.inW + 2 * pad - k) / stride + 1;
+  c.stem = stem;
+  c.w_off = P->weight_floats;
+  c.c_off = P->chan_floats;
+  P->weight_floats += (size_t)c.cout * k * k * cin;
+  P->chan_floats += c.cout;
+  c.need_dgrad = !stem;
+  c.dgrad_accum = false;
+  c.y_off = 0;
+  P->convs.push_back(c);
+  Op o = {0, (int)P->convs.size() - 1};
+  P->ops.push_back(o);
+  return o.idx;
+}
+
+int add_pool(tbn_backbone_plan* P, int kind, int inbuf, int outbuf, int out_choff, int stride, int pad) {
+  Pool p;
+  p.kind = kind;
+  p.inbuf = inbuf;
+  p.outbuf = outbuf;
+  p.out_choff = out_choff;
+  p.stride = stride;
+  p.pad = pad;
+  p.argmax_off = 0;
+  p.bwd_accum = false;
+  P->pools.push_back(p);
+  Op o = {1, (int)P->pools.size() - 1};
+  P->ops.push_back(o);
+  return o.idx;
+}
+
+void build_graph(tbn_backbone_plan* P) {
+  const int cin0 = P->cin0;
+  P->cp = (cin0 + 3) / 4 * 4;
+  P->kw = (7 * P->cp + 31) / 32 * 32;
+  P->weight_floats = P->chan_floats = 0;
+  const int x0 = add_buf(P, P->H, P->W, P->cp);
+  // stem
+  int h1 = (P->H + 6 - 7) / 2 + 1, w1 = (P->W + 6 - 7) / 2 + 1;
+  const int c1 = add_buf(P, h1, w1, 64);
+  {
+    std::string n = "conv1_7x7_s2";
+    int co = 64, db = c1, dc = 0;
+    add_conv(P, 1, &n, &co, cin0, 7, 2, 3, x0, &db, &dc, true);
+  }
+  int hp = pool_out(h1, 3, 2, 0, true), wp = pool_out(w1, 3, 2, 0, true);
+  const int p1 = add_buf(P, hp, wp, 64);
+  add_pool(P, 1, c1, p1, 0, 2, 0);
+  const int c2r = add_buf(P, hp, wp, 64);
+  {
+    std::string n = "conv2_3x3_reduce";
+    int co = 64, db = c2r, dc = 0;
+    add_conv(P, 1, &n, &co, 64, 1, 1, 0, p1, &db, &dc, false);
+  }
+  const int c2 = add_buf(P, hp, wp, 192);
+  {
+    std::string n = "conv2_3x3";
+    int co = 192, db = c2, dc = 0;
+    add_conv(P, 1, &n, &co, 64, 3, 1, 1, c2r, &db, &dc, false);
+  }
+  int h = pool_out(hp, 3, 2, 0, true), w = pool_out(wp, 3, 2, 0, true);
+  int x = add_buf(P, h, w, 192);
+  add_pool(P, 1, c2, x, 0, 2, 0);
+
+  for (int bi = 0; bi < kNumBlocks; ++bi) {
+    const BlockSpec& B = kBlocks[bi];
+    const std::string pre = std::string("inception_") + B.name;
+    int oh = h, ow = w;
+    if (B.stride == 2) {
+      oh = (h + 2 - 3) / 2 + 1;
+      ow = (w + 2 - 3) / 2 + 1;
+    }
+    const int ctot = B.c1 + B.c3 + B.cd2 + (B.pool == 2 ? B.cin : B.cp);
+    const int O = add_buf(P, oh, ow, ctot);
+    const int T1 = add_buf(P, h, w, B.c3r);
+    const int T2 = add_buf(P, h, w, B.cdr);
+    const int T3 = add_buf(P, h, w, B.cd1);
+    // fused 1x1 group on the block input
+    {
+      std::string names[3];
+      int couts[3], db[3], dc[3], n = 0;
+      if (B.c1) {
+        names[n] = pre + "_1x1";
+        couts[n] = B.c1;
+        db[n] = O;
+        dc[n] = 0;
+        ++n;
+      }
+      names[n] = pre + "_3x3_reduce";
+      couts[n] = B.c3r;
+      db[n] = T1;
+      dc[n] = 0;
+      ++n;
+      names[n] = pre + "_double_3x3_reduce";
+      couts[n] = B.cdr;
+      db[n] = T2;
+      dc[n] = 0;
+      ++n;
+      add_conv(P, n, names, couts, B.cin, 1, 1, 0, x, db, dc, false);
+    }
+    {
+      std::string n = pre + "_3x3";
+      int co = B.c3, db = O, dc = B.c1;
+      add_conv(P, 1, &n, &co, B.c3r, 3, B.stride, 1, T1, &db, &dc, false);
+    }
+    {
+      std::string n = pre + "_double_3x3_1";
+      int co = B.cd1, db = T3, dc = 0;
+      add_conv(P, 1, &n, &co, B.cdr, 3, 1, 1, T2, &db, &dc, false);
+    }
+    {
+      std::string n = pre + "_double_3x3_2";
+      int co = B.cd2, db = O, dc = B.c1 + B.c3;
+      add_conv(P, 1, &n, &co, B.cd1, 3, B.stride, 1, T3, &db, &dc, false);
+    }
+    if (B.pool == 2) {
+      add_pool(P, 1, x, O, B.c1 + B.c3 + B.cd2, 2, 0);
+    } else {
+      const int XP = add_buf(P, h, w, B.cin);
+      add_pool(P, B.pool == 0 ? 0 : 1, x, XP, 0, 1, 1);
+      std::string n = pre + "_pool_proj";
+      int co = B.cp, db = O, dc = B.c1 + B.c3 + B.cd2;
+      add_conv(P, 1, &n, &co, B.cin, 1, 1, 0, XP, &db, &dc, false);
+    }
+    x = O;
+    h = oh;
+    w = ow;
+  }
+  P->out_buf = x;
+
+  // backward write order: walk ops in reverse, first writer of a d-buffer overwrites, later ones add
+  std::vector<char> written(P->bufs.size(), 0);
+  for (int i = (int)P->ops.size() - 1; i >= 0; --i) {
+    const Op& o = P->ops[i];
+    if (o.kind == 0) {
+      Conv& c = P->convs[o.idx];
+      if (c.need_dgrad) {
+        c.dgrad_accum = written[c.inbuf] != 0;
+        written[c.inbuf] = 1;
+      }
+    } else {
+      Pool& p = P->pools[o.idx];
+      p.bwd_accum = written[p.inbuf] != 0;
+      written[p.inbuf] = 1;
+    }
+  }
+}
+
+void plan_memory(tbn_backbone_plan* P) {
+  const size_t R = P->frames;
+  size_t off = 0;
+  auto take = [&](size_t n) {
+    size_t o = off;
+    off += (n + 63) / 64 * 64;  // 256-B aligned float regions
+    return o;
+  };
+  for (auto& b : P->bufs) b.off = take(R * b.H * b.W * b.C);
+  P->x0_off = P->bufs[0].off;
+  P->stats_off = take(4 * P->chan_floats);  // mean | rstd | scale | shift
+  // per-layer tiles and scratch sizes
+  size_t partial = 0, wsplit = 0, wtf = 0;
+  for (auto& c : P->convs) {
+    const int M = (int)(R * c.outH * c.outW);
+    const int K = c.stem ? 7 * P->kw : c.k * c.k * c.cin;
+    tbn_conv_pick_tile(M, c.cout, K, &c.mt, &c.nt);
+    size_t a = (size_t)cdiv(M, 128 * c.mt) * 2 * c.cout;
+    size_t bparts = (size_t)tbn_bn_bwd_parts(M, c.cout) * 2 * c.cout;
+    if (a > partial) partial = a;
+    if (bparts > partial) partial = bparts;
+    const int taps = c.stem ? 7 : c.k * c.k, ci = c.stem ? P->kw : c.cin;
+    size_t ws = tbn_wgrad_workspace_floats(M, c.cout, ci, taps);
+    if (ws > wsplit) wsplit = ws;
+    if (c.need_dgrad) {
+      const int Md = (int)(R * c.inH * c.inW);
+      tbn_conv_pick_tile(Md, c.cin, c.k * c.k * c.cout, &c.d_mt, &c.d_nt);
+      size_t wt = (size_t)c.cout * c.k * c.k * c.cin;
+      if (wt > wtf) wtf = wt;
+    }
+  }
+  P->partial_floats = partial;
+  P->wsplit_floats = wsplit;
+  P->wt_floats = wtf;
+  P->partial_off = take(partial);
+  P->wpack_off = take((size_t)64 * 7 * P->kw);
+  P->eval_floats = off;
+  // training-only regions
+  for (auto& c : P->convs) c.y_off = take(R * c.outH * c.outW * c.cout);
+  for (size_t i = 1; i < P->bufs.size(); ++i) {
+    if ((int)i == P->out_buf) continue;  // gradient of the final feature map is supplied by the caller
+    P->bufs[i].doff = take(R * P->bufs[i].H * P->bufs[i].W * P->bufs[i].C);
+  }
+  P->coef_off = take(3 * 1024);
+  P->wsplit_off = take(wsplit);
+  P->wt_off = take(wtf);
+  P->dwpack_off = take((size_t)64 * 7 * P->kw);
+  size_t bytes = off * sizeof(float);
+  P->argmax_bytes_off = bytes;
+  for (auto& p : P->pools)
+    if (p.kind == 1) {
+      const Buf& ob = P->bufs[p.outbuf];
+      const Buf& ib = P->bufs[p.inbuf];
+      p.argmax_off = bytes;
+      bytes += align_up(R * ob.H * ob.W * ib.C, 256);
+    }
+  P->total_bytes_train = bytes;
+  P->total_bytes_eval = P->eval_floats * sizeof(float);
+}
+
+}  // namespace
+
+extern "C" {
+
+int tbn_backbone_plan_create(int in_channels, int frames, int height, int width, tbn_backbone_plan** out) {
+  TBN_REQUIRE(out != nullptr, "plan_create: null out");
+  TBN_REQUIRE(in_channels >= 1 && in_channels <= 16 && frames >= 1 && height >= 32 && width >= 32,
+              "plan_create: unsupported shape (C=%d, frames=%d, %dx%d)", in_channels, frames, height, width);
+  TBN_REQUIRE((long)frames * height * width < (1l << 31) / 4, "plan_create: too many pixels per call (chunk the batch)");
+  tbn_backbone_plan* P = new tbn_backbone_plan();
+  P->cin0 = in_channels;
+  P->frames = frames;
+  P->H = height;
+  P->W = width;
+  build_graph(P);
+  plan_memory(P);
+  *out = P;
+  return TBN_OK;
+}
+
+void tbn_backbone_plan_destroy(tbn_backbone_plan* p) { delete p; }
+
+int tbn_backbone_num_convs(const tbn_backbone_plan* P) {
+  int n = 0;
+  for (auto& c : P->convs) n += c.nparts;
+  return n;
+}
+
+int tbn_backbone_conv_info(const tbn_backbone_plan* P, int idx, tbn_conv_info* info) {
+  TBN_REQUIRE(info != nullptr, "conv_info: null info");
+  int n = 0;
+  for (auto& c : P->convs) {
+    size_t w = c.w_off, ch = c.c_off;
+    for (int i = 0; i < c.nparts; ++i) {
+      if (n == idx) {
+        memset(info, 0, sizeof(*info));
+        snprintf(info->name, sizeof(info->name), "%s", c.names[i].c_str());
+        info->cin = c.cin;
+        info->cout = c.couts[i];
+        info->ksize = c.k;
+        info->stride = c.stride;
+        info->pad = c.pad;
+        info->weight_offset = w;
+        info->channel_offset = ch;
+        return TBN_OK;
+      }
+      w += (size_t)c.couts[i] * c.k * c.k * c.cin;
+      ch += c.couts[i];
+      ++n;
+    }
+  }
+  tbn_set_error("conv_info: index %d out of range", idx);
+  return TBN_ERR_ARG;
+}
+
+size_t tbn_backbone_weight_floats(const tbn_backbone_plan* P) { return P->weight_floats; }
+size_t tbn_backbone_channel_floats(const tbn_backbone_plan* P) { return P->chan_floats; }
+size_t tbn_backbone_workspace_bytes(const tbn_backbone_plan* P, int training) {
+  return training ? P->total_bytes_train : P->total_bytes_eval;
+}
+int tbn_backbone_out_shape(const tbn_backbone_plan* P, int* h, int* w, int* c) {
+  const Buf& b = P->bufs[P->out_buf];
+  if (h) *h = b.H;
+  if (w) *w = b.W;
+  if (c) *c = b.C;
+  return TBN_OK;
+}
+
+#define TBN_TRY(expr)            \
+  do {                           \
+    int rc__ = (expr);           \
+    if (rc__ != TBN_OK) return rc__; \
+  } while (0)
+
+int tbn_backbone_forward(const tbn_backbone_plan* P, int training, const float* x_nchw,
+                         const tbn_backbone_params* prm, void* workspace, size_t workspace_bytes,
+                         float** features_out, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  TBN_REQUIRE(P && x_nchw && prm && workspace && features_out, "backbone_forward: null argument");
+  TBN_REQUIRE(workspace_bytes >= tbn_backbone_workspace_bytes(P, training), "backbone_forward: workspace too small");
+  TBN_REQUIRE(((uintptr_t)workspace & 255) == 0, "backbone_forward: workspace must be 256-B aligned");
+  float* ws = (float*)workspace;
+  const int R = P->frames;
+  float* mean = ws + P->stats_off;
+  float* rstd = mean + P->chan_floats;
+  float* scale = rstd + P->chan_floats;
+  float* shift = scale + P->chan_floats;
+  float* wpack = ws + P->wpack_off;
+
+  TBN_TRY(tbn_launch_nchw_to_nhwc_pad(x_nchw, ws + P->x0_off, R, P->cin0, P->H, P->W, P->cp, st));
+  TBN_TRY(tbn_launch_pack_stem_weight(prm->weight + P->convs[0].w_off, wpack, 64, P->cin0, P->cp, P->kw, st));
+  if (!training)
+    TBN_TRY(tbn_launch_bn_fold(prm->gamma, prm->beta, prm->running_mean, prm->running_var, nullptr, prm->eps, scale,
+                               shift, (int)P->chan_floats, st));
+
+  for (const Op& o : P->ops) {
+    if (o.kind == 0) {
+      const Conv& c = P->convs[o.idx];
+      const Buf& ib = P->bufs[c.inbuf];
+      ConvP p;
+      memset(&p, 0, sizeof(p));
+      p.in = ws + ib.off;
+      p.in_ld = ib.C;
+      p.N = R;
+      p.H = c.inH;
+      p.W = c.inW;
+      p.OH = c.outH;
+      p.OW = c.outW;
+      p.Cout = c.cout;
+      p.stride = c.stride;
+      p.pad = c.pad;
+      p.up = 1;
+      p.M = R * c.outH * c.outW;
+      p.bias = prm->bias + c.c_off;
+      if (c.stem) {
+        p.wt = wpack;
+        p.Cin = P->kw;
+        p.R = 7;
+        p.S = 1;
+        p.K = 7 * P->kw;
+        p.cp = P->cp;
+      } else {
+        p.wt = prm->weight + c.w_off;
+        p.Cin = c.cin;
+        p.R = p.S = c.k;
+        p.K = c.k * c.k * c.cin;
+      }
+      Seg zs[3];
+      int col = 0;
+      for (int i = 0; i < c.nparts; ++i) {
+        const Buf& db = P->bufs[c.dst_buf[i]];
+        zs[i].ptr = ws + db.off + c.dst_choff[i];
+        zs[i].ld = db.C;
+        zs[i].col_begin = col;
+        col += c.couts[i];
+      }
+      if (training) {
+        float* y = ws + c.y_off;
+        p.mode = CONV_EPI_STATS;
+        p.nseg = 1;
+        p.seg[0].ptr = y;
+        p.seg[0].ld = c.cout;
+        p.seg[0].col_begin = 0;
+        p.stat_partial = ws + P->partial_off;
+        TBN_TRY(tbn_launch_conv(p, c.stem, c.mt, c.nt, st));
+        TBN_TRY(tbn_launch_bn_finalize(ws + P->partial_off, cdiv(p.M, 128 * c.mt), p.M, c.cout, prm->gamma + c.c_off,
+                                       prm->beta + c.c_off, prm->running_mean + c.c_off, prm->running_var + c.c_off,
+                                       prm->momentum, prm->eps, mean + c.c_off, rstd + c.c_off, scale + c.c_off,
+                                       shift + c.c_off, st));
+        TBN_TRY(tbn_launch_bn_apply(y, p.M, c.cout, scale + c.c_off, shift + c.c_off, zs, c.nparts, st));
+      } else {
+        p.mode = CONV_EPI_EVAL;
+        p.scale = scale + c.c_off;
+        p.shift = shift + c.c_off;
+        p.nseg = c.nparts;
+        for (int i = 0; i < c.nparts; ++i) p.seg[i] = zs[i];
+        TBN_TRY(tbn_launch_conv(p, c.stem, c.mt, c.nt, st));
+      }
+    } else {
+      const Pool& q = P->pools[o.idx];
+      const Buf& ib = P->bufs[q.inbuf];
+      const Buf& ob = P->bufs[q.outbuf];
+      if (q.kind == 0) {
+        TBN_TRY(tbn_launch_avgpool3_fwd(ws + ib.off, ib.C, ws + ob.off + q.out_choff, ob.C, R, ib.H, ib.W, ib.C, 0, st));
+      } else {
+        uint8_t* am = training ? (uint8_t*)workspace + q.argmax_off : nullptr;
+        TBN_TRY(tbn_launch_maxpool_fwd(ws + ib.off, ib.C, ws + ob.off + q.out_choff, ob.C, am, R, ib.H, ib.W, ib.C,
+                                       ob.H, ob.W, q.stride, q.pad, st));
+      }
+    }
+  }
+  *features_out = ws + P->bufs[P->out_buf].off;
+  return TBN_OK;
+}
+
+int tbn_backbone_backward(const tbn_backbone_plan* P, const float* dfeatures, const tbn_backbone_params* prm,
+                          const tbn_backbone_grads* g, void* workspace, size_t workspace_bytes, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  TBN_REQUIRE(P && dfeatures && prm && g && workspace, "backbone_backward: null argument");
+  TBN_REQUIRE(g->dweight && g->dbias, "backbone_backward: dweight/dbias required");
+  TBN_REQUIRE(workspace_bytes >= P->total_bytes_train, "backbone_backward: workspace too small");
+  float* ws = (float*)workspace;
+  const int R = P->frames;
+  float* mean = ws + P->stats_off;
+  float* rstd = mean + P->chan_floats;
+  float* scale = rstd + P->chan_floats;
+  float* shift = scale + P->chan_floats;
+  float* partial = ws + P->partial_off;
+  float* coef = ws + P->coef_off;
+  auto dptr = [&](int buf) -> const float* {
+    return buf == P->out_buf ? dfeatures : ws + P->bufs[buf].doff;
+  };
+
+  for (int oi = (int)P->ops.size() - 1; oi >= 0; --oi) {
+    const Op& o = P->ops[oi];
+    if (o.kind == 1) {
+      const Pool& q = P->pools[o.idx];
+      const Buf& ib = P->bufs[q.inbuf];
+      const Buf& ob = P->bufs[q.outbuf];
+      if (q.inbuf == 0) continue;
+      float* din = ws + ib.doff;
+      if (q.kind == 0) {
+        TBN_TRY(tbn_launch_avgpool3_fwd(dptr(q.outbuf) + q.out_choff, ob.C, din, ib.C, R, ib.H, ib.W, ib.C, q.bwd_accum,
+                                        st));
+      } else {
+        TBN_TRY(tbn_launch_maxpool_bwd(dptr(q.outbuf) + q.out_choff, ob.C, (const uint8_t*)workspace + q.argmax_off,
+                                       din, ib.C, R, ib.H, ib.W, ib.C, ob.H, ob.W, q.stride, q.pad, q.bwd_accum, st));
+      }
+      continue;
+    }
+    const Conv& c = P->convs[o.idx];
+    const Buf& ib = P->bufs[c.inbuf];
+    const int M = R * c.outH * c.outW;
+    float* y = ws + c.y_off;  // becomes dy in place
+    CSeg dz[3];
+    int col = 0;
+    for (int i = 0; i < c.nparts; ++i) {
+      const Buf& db = P->bufs[c.dst_buf[i]];
+      dz[i].ptr = dptr(c.dst_buf[i]) + c.dst_choff[i];
+      dz[i].ld = db.C;
+      dz[i].col_begin = col;
+      col += c.couts[i];
+    }
+    TBN_TRY(tbn_launch_bn_bwd_reduce(dz, c.nparts, y, M, c.cout, scale + c.c_off, shift + c.c_off, mean + c.c_off,
+                                     rstd + c.c_off, partial, st));
+    const bool bn_grad = g->dgamma && g->dbeta && (g->bn_grad_layers == 2 || (g->bn_grad_layers == 1 && o.idx == 0));
+    TBN_TRY(tbn_launch_bn_bwd_finalize(partial, tbn_bn_bwd_parts(M, c.cout), M, c.cout, scale + c.c_off,
+                                       mean + c.c_off, rstd + c.c_off, coef, bn_grad ? g->dgamma + c.c_off : nullptr,
+                                       bn_grad ? g->dbeta + c.c_off : nullptr, g->dbias + c.c_off, st));
+    TBN_TRY(tbn_launch_bn_bwd_apply(dz, c.nparts, y, M, c.cout, scale + c.c_off, shift + c.c_off, coef, y, st));
+    // weight gradient
+    {
+      WgradP wp;
+      memset(&wp, 0, sizeof(wp));
+      wp.dy = y;
+      wp.dy_ld = c.cout;
+      wp.x = ws + ib.off;
+      wp.x_ld = ib.C;
+      wp.N = R;
+      wp.H = c.inH;
+      wp.W = c.inW;
+      wp.OH = c.outH;
+      wp.OW = c.outW;
+      wp.Cout = c.cout;
+      wp.stride = c.stride;
+      wp.pad = c.pad;
+      wp.M = M;
+      if (c.stem) {
+        wp.Cin = P->kw;
+        wp.R = 7;
+        wp.S = 1;
+        wp.taps = 7;
+        wp.cp = P->cp;
+        float* dwp = ws + P->dwpack_off;
+        TBN_TRY(tbn_launch_wgrad(wp, 1, dwp, ws + P->wsplit_off, st));
+        TBN_TRY(tbn_launch_unpack_stem_wgrad(dwp, g->dweight + c.w_off, 64, P->cin0, P->cp, P->kw, st));
+      } else {
+        wp.Cin = c.cin;
+        wp.R = wp.S = c.k;
+        wp.taps = c.k * c.k;
+        TBN_TRY(tbn_launch_wgrad(wp, 0, g->dweight + c.w_off, ws + P->wsplit_off, st));
+      }
+    }
+    // data gradient: conv of dy with flipped / transposed weights (zero-insertion for stride 2)
+    if (c.need_dgrad) {
+      float* wt = ws + P->wt_off;
+      TBN_TRY(tbn_launch_weight_flip_transpose(prm->weight + c.w_off, wt, c.cout, c.k * c.k, c.cin, st));
+      ConvP p;
+      memset(&p, 0, sizeof(p));
+      p.in = y;
+      p.in_ld = c.cout;
+      p.wt = wt;
+      p.N = R;
+      p.H = c.outH;
+      p.W = c.outW;
+      p.OH = c.inH;
+      p.OW = c.inW;
+      p.Cin = c.cout;
+      p.Cout = c.cin;
+      p.R = p.S = c.k;
+      p.stride = 1;
+      p.pad = c.k - 1 - c.pad;
+      p.up = c.stride;
+      p.M = R * c.inH * c.inW;
+      p.K = c.k * c.k * c.cout;
+      p.mode = CONV_EPI_PLAIN;
+      p.flags = c.dgrad_accum ? CONV_FLAG_ACCUM : 0;
+      p.nseg = 1;
+      p.seg[0].ptr = ws + ib.doff;
+      p.seg[0].ld = ib.C;
+      p.seg[0].col_begin = 0;
+      TBN_TRY(tbn_launch_conv(p, 0, c.d_mt, c.d_nt, st));
+    }
+  }
+  return TBN_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,268 @@
+// Pooling, layout and stem-weight packing kernels (NHWC fp32, 16 B per lane, HBM-bound).
+//
+// Reference ops (core/models/bn_inception_audio.py):
+//   MaxPool2d(3, stride 2, ceil_mode=True)          pool1/pool2, inception_3c/4e pass-through (:21-23,32-34,155-157,327-329)
+//   MaxPool2d(3, stride 1, pad 1)                   inception_5b_pool (:394-396)
+//   AvgPool2d(3, stride 1, pad 1, count_include_pad) inception_{3a,3b,4a-4d,5a}_pool (:86-88 ...)
+//   F.avg_pool2d over (H,1) or (H,W)                 BNInception.logits (core/models/bn_inception.py:16-35)
+// Max-pool forward also stores the in-window argmax (uint8, first maximum in scan order like
+// ATen) so the backward is a deterministic gather (no float atomics).
+#include "tbn_common.h"
+#include "tbn_kernels.h"
+
+static inline int ew_grid(size_t items) {
+  size_t g = (items + 255) / 256;
+  return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g));
+}
+
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ in, int in_ld,
+                                                          float* __restrict__ out, int out_ld,
+                                                          uint8_t* __restrict__ argmax, int N, int H, int W, int C,
+                                                          int OH, int OW, int stride, int pad) {
+  const int G = C >> 2;
+  const size_t total = (size_t)N * OH * OW * G;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int g = (int)(i % G);
+    size_t pix = i / G;
+    const int ox = (int)(pix % OW);
+    pix /= OW;
+    const int oy = (int)(pix % OH), n = (int)(pix / OH);
+    const int y0 = oy * stride - pad, x0 = ox * stride - pad;
+    float4 best = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    int bx = 0, by = 0, bz = 0, bw = 0;
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        const int iy = y0 + r, ix = x0 + s;
+        if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
+          const float4 v = *reinterpret_cast<const float4*>(in + ((size_t)(n * H + iy) * W + ix) * in_ld + g * 4);
+          const int k = r * 3 + s;
+          if (v.x > best.x || v.x != v.x) { best.x = v.x; bx = k; }
+          if (v.y > best.y || v.y != v.y) { best.y = v.y; by = k; }
+          if (v.z > best.z || v.z != v.z) { best.z = v.z; bz = k; }
+          if (v.w > best.w || v.w != v.w) { best.w = v.w; bw = k; }
+        }
+      }
+    const size_t opix = (size_t)(n * OH + oy) * OW + ox;
+    *reinterpret_cast<float4*>(out + opix * out_ld + g * 4) = best;
+    if (argmax != nullptr)
+      *reinterpret_cast<uint32_t*>(argmax + opix * C + g * 4) =
+          (uint32_t)bx | ((uint32_t)by << 8) | ((uint32_t)bz << 16) | ((uint32_t)bw << 24);
+  }
+}
+
+int tbn_launch_maxpool_fwd(const float* in, int in_ld, float* out, int out_ld, uint8_t* argmax, int N, int H, int W,
+                           int C, int OH, int OW, int stride, int pad, hipStream_t st) {
+  TBN_REQUIRE(C % 4 == 0 && in_ld % 4 == 0 && out_ld % 4 == 0, "maxpool: C / pitches must be multiples of 4");
+  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(ew_grid((size_t)N * OH * OW * C / 4)), dim3(256), 0, st, in, in_ld, out,
+                     out_ld, argmax, N, H, W, C, OH, OW, stride, pad);
+  TBN_CHECK_LAUNCH("maxpool_fwd");
+  return TBN_OK;
+}
+
+// gather form: each input element sums dout of the (<= 4 or 9) windows whose argmax it is
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ dout, int dout_ld,
+                                                          const uint8_t* __restrict__ argmax,
+                                                          float* __restrict__ din, int din_ld, int N, int H, int W,
+                                                          int C, int OH, int OW, int stride, int pad, int accumulate) {
+  const int G = C >> 2;
+  const size_t total = (size_t)N * H * W * G;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int g = (int)(i % G);
+    size_t pix = i / G;
+    const int ix = (int)(pix % W);
+    pix /= W;
+    const int iy = (int)(pix % H), n = (int)(pix / H);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    // windows oy with oy*stride - pad <= iy <= oy*stride - pad + 2
+    const int oy_hi = min(OH - 1, (iy + pad) / stride);
+    const int ox_hi = min(OW - 1, (ix + pad) / stride);
+    for (int oy = oy_hi; oy >= 0; --oy) {
+      const int r = iy - (oy * stride - pad);
+      if (r > 2) break;
+      for (int ox = ox_hi; ox >= 0; --ox) {
+        const int s = ix - (ox * stride - pad);
+        if (s > 2) break;
+        const uint32_t k = (uint32_t)(r * 3 + s);
+        const size_t opix = (size_t)(n * OH + oy) * OW + ox;
+        const uint32_t am = *reinterpret_cast<const uint32_t*>(argmax + opix * C + g * 4);
+        const float4 d = *reinterpret_cast<const float4*>(dout + opix * dout_ld + g * 4);
+        if ((am & 0xff) == k) acc.x += d.x;
+        if (((am >> 8) & 0xff) == k) acc.y += d.y;
+        if (((am >> 16) & 0xff) == k) acc.z += d.z;
+        if ((am >> 24) == k) acc.w += d.w;
+      }
+    }
+    float4* o = reinterpret_cast<float4*>(din + ((size_t)(n * H + iy) * W + ix) * din_ld + g * 4);
+    if (accumulate) {
+      const float4 prev = *o;
+      acc.x += prev.x; acc.y += prev.y; acc.z += prev.z; acc.w += prev.w;
+    }
+    *o = acc;
+  }
+}
+
+int tbn_launch_maxpool_bwd(const float* dout, int dout_ld, const uint8_t* argmax, float* din, int din_ld, int N,
+                           int H, int W, int C, int OH, int OW, int stride, int pad, int accumulate, hipStream_t st) {
+  TBN_REQUIRE(C % 4 == 0 && din_ld % 4 == 0 && dout_ld % 4 == 0, "maxpool_bwd: C / pitches must be multiples of 4");
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(ew_grid((size_t)N * H * W * C / 4)), dim3(256), 0, st, dout, dout_ld,
+                     argmax, din, din_ld, N, H, W, C, OH, OW, stride, pad, accumulate);
+  TBN_CHECK_LAUNCH("maxpool_bwd");
+  return TBN_OK;
+}
+
+// 3x3 / stride 1 / pad 1 / count_include_pad average.  Self-adjoint, so it is its own backward.
+__global__ __launch_bounds__(256) void avgpool3_kernel(const float* __restrict__ in, int in_ld,
+                                                       float* __restrict__ out, int out_ld, int N, int H, int W, int C,
+                                                       int accumulate) {
+  const int G = C >> 2;
+  const size_t total = (size_t)N * H * W * G;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int g = (int)(i % G);
+    size_t pix = i / G;
+    const int x = (int)(pix % W);
+    pix /= W;
+    const int y = (int)(pix % H), n = (int)(pix / H);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int r = -1; r <= 1; ++r)
+#pragma unroll
+      for (int s = -1; s <= 1; ++s) {
+        const int iy = y + r, ix = x + s;
+        if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
+          const float4 v = *reinterpret_cast<const float4*>(in + ((size_t)(n * H + iy) * W + ix) * in_ld + g * 4);
+          acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+      }
+    const float k = 1.f / 9.f;
+    acc.x *= k; acc.y *= k; acc.z *= k; acc.w *= k;
+    float4* o = reinterpret_cast<float4*>(out + ((size_t)(n * H + y) * W + x) * out_ld + g * 4);
+    if (accumulate) {
+      const float4 prev = *o;
+      acc.x += prev.x; acc.y += prev.y; acc.z += prev.z; acc.w += prev.w;
+    }
+    *o = acc;
+  }
+}
+
+int tbn_launch_avgpool3_fwd(const float* in, int in_ld, float* out, int out_ld, int N, int H, int W, int C,
+                            int accumulate, hipStream_t st) {
+  TBN_REQUIRE(C % 4 == 0 && in_ld % 4 == 0 && out_ld % 4 == 0, "avgpool: C / pitches must be multiples of 4");
+  hipLaunchKernelGGL(avgpool3_kernel, dim3(ew_grid((size_t)N * H * W * C / 4)), dim3(256), 0, st, in, in_ld, out,
+                     out_ld, N, H, W, C, accumulate);
+  TBN_CHECK_LAUNCH("avgpool3");
+  return TBN_OK;
+}
+
+// mean over (H,W) [freq_only=0 -> out (N,C)] or over H only [freq_only=1 -> out (N,W,C)]
+__global__ __launch_bounds__(256) void spatial_mean_fwd_kernel(const float* __restrict__ in, int in_ld,
+                                                               float* __restrict__ out, int out_ld, int N, int H,
+                                                               int W, int C, int freq_only) {
+  const int G = C >> 2;
+  const int OW = freq_only ? W : 1;
+  const size_t total = (size_t)N * OW * G;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int g = (int)(i % G);
+    const size_t q = i / G;
+    const int x = (int)(q % OW), n = (int)(q / OW);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int x0 = freq_only ? x : 0, x1 = freq_only ? x + 1 : W;
+    for (int y = 0; y < H; ++y)
+      for (int xx = x0; xx < x1; ++xx) {
+        const float4 v = *reinterpret_cast<const float4*>(in + ((size_t)(n * H + y) * W + xx) * in_ld + g * 4);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+      }
+    const float k = 1.f / (float)(freq_only ? H : H * W);
+    acc.x *= k; acc.y *= k; acc.z *= k; acc.w *= k;
+    *reinterpret_cast<float4*>(out + (size_t)q * out_ld + g * 4) = acc;
+  }
+}
+
+int tbn_launch_spatial_mean_fwd(const float* in, int in_ld, float* out, int out_ld, int N, int H, int W, int C,
+                                int freq_only, hipStream_t st) {
+  TBN_REQUIRE(C % 4 == 0 && in_ld % 4 == 0 && out_ld % 4 == 0, "spatial_mean: C / pitches must be multiples of 4");
+  hipLaunchKernelGGL(spatial_mean_fwd_kernel, dim3(ew_grid((size_t)N * (freq_only ? W : 1) * C / 4)), dim3(256), 0,
+                     st, in, in_ld, out, out_ld, N, H, W, C, freq_only);
+  TBN_CHECK_LAUNCH("spatial_mean_fwd");
+  return TBN_OK;
+}
+
+__global__ __launch_bounds__(256) void spatial_mean_bwd_kernel(const float* __restrict__ dout, int dout_ld,
+                                                               float* __restrict__ din, int din_ld, int N, int H,
+                                                               int W, int C, int freq_only) {
+  const int G = C >> 2;
+  const size_t total = (size_t)N * H * W * G;
+  const float k = 1.f / (float)(freq_only ? H : H * W);
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int g = (int)(i % G);
+    size_t pix = i / G;
+    const int x = (int)(pix % W);
+    pix /= W;
+    const int n = (int)(pix / H);
+    const size_t q = freq_only ? (size_t)n * W + x : (size_t)n;
+    float4 v = *reinterpret_cast<const float4*>(dout + q * dout_ld + g * 4);
+    v.x *= k; v.y *= k; v.z *= k; v.w *= k;
+    *reinterpret_cast<float4*>(din + (i / G) * din_ld + g * 4) = v;
+  }
+}
+
+int tbn_launch_spatial_mean_bwd(const float* dout, int dout_ld, float* din, int din_ld, int N, int H, int W, int C,
+                                int freq_only, hipStream_t st) {
+  TBN_REQUIRE(C % 4 == 0 && din_ld % 4 == 0 && dout_ld % 4 == 0, "spatial_mean_bwd: bad C / pitches");
+  hipLaunchKernelGGL(spatial_mean_bwd_kernel, dim3(ew_grid((size_t)N * H * W * C / 4)), dim3(256), 0, st, dout,
+                     dout_ld, din, din_ld, N, H, W, C, freq_only);
+  TBN_CHECK_LAUNCH("spatial_mean_bwd");
+  return TBN_OK;
+}
+
+// NCHW (reference tensor layout, model.py:211-213) -> NHWC padded to Cp channels (zeros)
+__global__ __launch_bounds__(256) void nchw_to_nhwc_pad_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                               int N, int C, int H, int W, int Cp) {
+  const size_t hw = (size_t)H * W, total = (size_t)N * hw;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const size_t n = i / hw, p = i - n * hw;
+    float* o = out + i * Cp;
+    for (int c = 0; c < Cp; ++c) o[c] = c < C ? in[(n * C + c) * hw + p] : 0.f;
+  }
+}
+
+int tbn_launch_nchw_to_nhwc_pad(const float* in, float* out, int N, int C, int H, int W, int Cp, hipStream_t st) {
+  TBN_REQUIRE(Cp >= C && Cp % 4 == 0, "nchw_to_nhwc_pad: Cp must be >= C and a multiple of 4");
+  hipLaunchKernelGGL(nchw_to_nhwc_pad_kernel, dim3(ew_grid((size_t)N * H * W)), dim3(256), 0, st, in, out, N, C, H, W,
+                     Cp);
+  TBN_CHECK_LAUNCH("nchw_to_nhwc_pad");
+  return TBN_OK;
+}
+
+// stem weights [Cout][7][7][Cin] -> [Cout][7][KW]: filter row = 7*Cp floats (channel-padded), zero tail
+__global__ void pack_stem_weight_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin, int Cp,
+                                        int KW) {
+  const int total = Cout * 7 * KW;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int k = i % KW, r = (i / KW) % 7, co = i / (KW * 7);
+    const int s = k / Cp, c = k - s * Cp;
+    wp[i] = (s < 7 && c < Cin) ? w[((co * 7 + r) * 7 + s) * Cin + c] : 0.f;
+  }
+}
+__global__ void unpack_stem_wgrad_kernel(const float* __restrict__ dwp, float* __restrict__ dw, int Cout, int Cin,
+                                         int Cp, int KW) {
+  const int total = Cout * 49 * Cin;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int c = i % Cin, s = (i / Cin) % 7, r = (i / (Cin * 7)) % 7, co = i / (Cin * 49);
+    dw[i] = dwp[(co * 7 + r) * KW + s * Cp + c];
+  }
+}
+
+int tbn_launch_pack_stem_weight(const float* w, float* wp, int Cout, int Cin, int Cp, int KW, hipStream_t st) {
+  hipLaunchKernelGGL(pack_stem_weight_kernel, dim3(cdiv(Cout * 7 * KW, 256)), dim3(256), 0, st, w, wp, Cout, Cin, Cp,
+                     KW);
+  TBN_CHECK_LAUNCH("pack_stem_weight");
+  return TBN_OK;
+}
+int tbn_launch_unpack_stem_wgrad(const float* dwp, float* dw, int Cout, int Cin, int Cp, int KW, hipStream_t st) {
+  hipLaunchKernelGGL(unpack_stem_wgrad_kernel, dim3(cdiv(Cout * 49 * Cin, 256)), dim3(256), 0, st, dwp, dw, Cout, Cin,
+                     Cp, KW);
+  TBN_CHECK_LAUNCH("unpack_stem_wgrad");
+  return TBN_OK;
+}

@@ -1,0 +1,67 @@
+// Internal helpers shared by the HIP translation units of libtbn_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#define TBN_OK 0
+#define TBN_ERR_ARG (-1)
+#define TBN_ERR_LAUNCH (-2)
+#define TBN_ERR_UNSUPPORTED (-3)
+
+// thread-local last-error string (tbn_last_error() in the C-ABI)
+void tbn_set_error(const char* fmt, ...);
+
+#define TBN_REQUIRE(cond, ...)                   \
+  do {                                           \
+    if (!(cond)) {                               \
+      tbn_set_error(__VA_ARGS__);                \
+      return TBN_ERR_ARG;                        \
+    }                                            \
+  } while (0)
+
+#define TBN_CHECK_LAUNCH(what)                                                     \
+  do {                                                                             \
+    hipError_t e__ = hipGetLastError();                                            \
+    if (e__ != hipSuccess) {                                                       \
+      tbn_set_error("%s: launch failed: %s", what, hipGetErrorString(e__));        \
+      return TBN_ERR_LAUNCH;                                                       \
+    }                                                                              \
+  } while (0)
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// exact unsigned division by a runtime constant for dividends < 2^31:
+//   q = (m * mul) >> (31 + sh), sh = ceil(log2 d), mul = ceil(2^(31+sh) / d)  (fits 32 bits)
+struct FastDiv {
+  uint32_t mul, sh, d;
+};
+static inline FastDiv make_fastdiv(uint32_t d) {
+  FastDiv f;
+  f.d = d;
+  uint32_t sh = 0;
+  while ((1u << sh) < d) ++sh;
+  f.sh = sh;
+  uint64_t p = 1ull << (31 + sh);
+  f.mul = (uint32_t)((p + d - 1) / d);
+  return f;
+}
+__device__ __forceinline__ uint32_t fdiv(uint32_t m, FastDiv f) {
+  return (uint32_t)(((uint64_t)m * f.mul) >> (31 + f.sh));
+}
+
+// up to 3 destination column ranges of a conv / bn output (concat-slice writes)
+struct Seg {
+  float* ptr;     // base of column `col_begin`
+  int ld;         // floats between consecutive rows (pixels)
+  int col_begin;  // first logical output column written through this segment
+};
+struct CSeg {
+  const float* ptr;
+  int ld;
+  int col_begin;
+};

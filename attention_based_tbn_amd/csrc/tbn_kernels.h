@@ -1,0 +1,85 @@
+// Internal launch-level interface between the HIP kernels and the C-ABI / backbone engine.
+#pragma once
+#include "tbn_common.h"
+
+enum { CONV_EPI_PLAIN = 0, CONV_EPI_STATS = 1, CONV_EPI_EVAL = 2 };
+enum { CONV_FLAG_ACCUM = 1, CONV_FLAG_RELU = 2 };
+
+struct ConvP {
+  const float* in;
+  const float* wt;
+  const float* bias;      // may be null
+  const float* scale;     // EVAL epilogue
+  const float* shift;     // EVAL epilogue
+  float* stat_partial;    // STATS epilogue: [tiles_m][2][Cout]
+  Seg seg[3];
+  int nseg;
+  int in_ld;
+  int N, H, W;            // input spatial dims (for dgrad: dims of dy)
+  int OH, OW;
+  int Cin;                // K per tap (ROWMODE: padded filter-row length in floats)
+  int Cout;
+  int R, S, stride, pad, up;
+  int M, K;
+  int cp;                 // ROWMODE: channels per pixel of the padded NHWC input
+  int tiles_m, tiles_n;
+  int mode, flags;
+};
+
+struct WgradP {
+  const float* dy;
+  const float* x;
+  float* out;
+  int dy_ld, x_ld;
+  int N, H, W, OH, OW;
+  int Cin, Cout;          // per tap (ROWMODE: Cin = padded row length)
+  int R, S, stride, pad;
+  int taps;
+  int M, K;
+  int cp;
+  int tiles_co, tiles_ci;
+  int rows_per_split;
+  FastDiv div_ohw, div_ow;
+};
+
+// conv_igemm.hip
+void tbn_conv_pick_tile(int M, int Cout, int K, int* mt, int* nt);
+int tbn_launch_conv(ConvP p, int rowmode, int mt, int nt, hipStream_t st);
+void tbn_wgrad_plan(int M, int Cout, int Cin, int taps, int* mt, int* nt, int* splits, int* rows_per_split);
+size_t tbn_wgrad_workspace_floats(int M, int Cout, int Cin, int taps);
+int tbn_launch_wgrad(WgradP p, int rowmode, float* dw, float* workspace, hipStream_t st);
+int tbn_launch_weight_flip_transpose(const float* w, float* wt, int Cout, int taps, int Cin, hipStream_t st);
+
+// bn.hip
+int tbn_launch_bn_stats(const float* y, int ld, int P, int C, float* partial, int* nparts, hipStream_t st);
+int tbn_bn_stats_parts(int P, int C);
+int tbn_launch_bn_finalize(const float* partial, int nparts, int P, int C, const float* gamma, const float* beta,
+                           float* running_mean, float* running_var, float momentum, float eps, float* save_mean,
+                           float* save_rstd, float* scale, float* shift, hipStream_t st);
+int tbn_launch_bn_apply(const float* y, int P, int C, const float* scale, const float* shift, const Seg* segs,
+                        int nseg, hipStream_t st);
+int tbn_launch_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var, const float* bias,
+                       float eps, float* scale, float* shift, int C, hipStream_t st);
+int tbn_bn_bwd_parts(int P, int C);
+int tbn_launch_bn_bwd_reduce(const CSeg* dz, int nseg, const float* y, int P, int C, const float* scale,
+                             const float* shift, const float* mean, const float* rstd, float* partial, hipStream_t st);
+int tbn_launch_bn_bwd_finalize(const float* partial, int nparts, int P, int C, const float* scale, const float* mean,
+                               const float* rstd, float* coef, float* dgamma, float* dbeta, float* dbias,
+                               hipStream_t st);
+int tbn_launch_bn_bwd_apply(const CSeg* dz, int nseg, const float* y, int P, int C, const float* scale,
+                            const float* shift, const float* coef, float* dy, hipStream_t st);
+
+// pool.hip
+int tbn_launch_maxpool_fwd(const float* in, int in_ld, float* out, int out_ld, uint8_t* argmax, int N, int H, int W,
+                           int C, int OH, int OW, int stride, int pad, hipStream_t st);
+int tbn_launch_maxpool_bwd(const float* dout, int dout_ld, const uint8_t* argmax, float* din, int din_ld, int N,
+                           int H, int W, int C, int OH, int OW, int stride, int pad, int accumulate, hipStream_t st);
+int tbn_launch_avgpool3_fwd(const float* in, int in_ld, float* out, int out_ld, int N, int H, int W, int C,
+                            int accumulate, hipStream_t st);
+int tbn_launch_spatial_mean_fwd(const float* in, int in_ld, float* out, int out_ld, int N, int H, int W, int C,
+                                int freq_only, hipStream_t st);
+int tbn_launch_spatial_mean_bwd(const float* dout, int dout_ld, float* din, int din_ld, int N, int H, int W, int C,
+                                int freq_only, hipStream_t st);
+int tbn_launch_nchw_to_nhwc_pad(const float* in, float* out, int N, int C, int H, int W, int Cp, hipStream_t st);
+int tbn_launch_pack_stem_weight(const float* w, float* wp, int Cout, int Cin, int Cp, int KW, hipStream_t st);
+int tbn_launch_unpack_stem_wgrad(const float* dwp, float* dw, int Cout, int Cin, int Cp, int KW, hipStream_t st);

@@ -1,0 +1,190 @@
+/* libtbn_hip.so -- C-ABI of the MI355X (gfx950) TBN hot path.
+ *
+ * The reference (tridivb/attention_based_tbn) is pure Python on torch.nn and has no native
+ * interface; this is the boundary a maintainer binds with ctypes.  Every
+ * entry point lists the reference code it replaces.
+ *
+ * Conventions
+ *   - plain C: raw device pointers (fp32 unless noted), explicit sizes / pitches, `void* stream`
+ *     is a hipStream_t (pass PyTorch's current stream); no torch types, no allocation, no
+ *     synchronisation, no global device state inside -- the caller owns every buffer including
+ *     workspaces (sizes from the *_bytes / *_floats queries);
+ *   - returns 0 on success, <0 on error (TBN_ERR_*); message via tbn_last_error() (thread-local);
+ *     never throws; re-entrant; results are deterministic (no float atomics);
+ *   - activations are NHWC with an explicit pitch `ld` (floats between pixels) so operators read
+ *     and write channel slices of concat buffers; conv weights are [Cout][R][S][Cin], i.e. the
+ *     memory of an OIHW torch parameter in channels_last format.
+ */
+#ifndef TBN_HIP_H
+#define TBN_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TBN_ERR_ARG (-1)
+#define TBN_ERR_LAUNCH (-2)
+#define TBN_ERR_UNSUPPORTED (-3)
+
+int tbn_version(void);
+const char* tbn_last_error(void);
+
+/* ---- BN-Inception backbone engine -------------------------------------------------------------
+ * replaces: BNInception.features() as instantiated by reference core/models/bn_inception.py:38-107
+ * (graph core/models/bn_inception_audio.py:58-404,437-1003 with the 7x7 stem), called from
+ * TBNModel.forward core/models/model.py:211-213, and its autograd backward (core/tools/train.py:81).
+ * A plan is host-only metadata for one (in_channels, frames, H, W). */
+typedef struct tbn_backbone_plan tbn_backbone_plan;
+
+typedef struct {
+  char name[64];          /* reference module name, e.g. "inception_3a_1x1" (+"_bn" for its BatchNorm) */
+  int cin, cout, ksize, stride, pad;
+  size_t weight_offset;   /* floats into the flat weight array: this conv's [cout][k][k][cin] block */
+  size_t channel_offset;  /* floats into each flat per-channel array (bias, gamma, beta, mean, var) */
+} tbn_conv_info;
+
+typedef struct {
+  const float* weight;        /* flat conv weights, tbn_backbone_weight_floats() */
+  const float* bias;          /* flat conv biases, tbn_backbone_channel_floats() */
+  const float* gamma;         /* BatchNorm weight */
+  const float* beta;          /* BatchNorm bias */
+  float* running_mean;        /* updated in training mode (momentum) */
+  float* running_var;
+  float momentum;             /* 0.1 */
+  float eps;                  /* 1e-5 */
+} tbn_backbone_params;
+
+typedef struct {
+  float* dweight;             /* same layout as weight; fully overwritten */
+  float* dbias;
+  float* dgamma;              /* may be NULL */
+  float* dbeta;               /* may be NULL */
+  int bn_grad_layers;         /* 0 none, 1 first BN only ("partialbn", model.py:164-176), 2 all */
+} tbn_backbone_grads;
+
+int tbn_backbone_plan_create(int in_channels, int frames, int height, int width, tbn_backbone_plan** plan);
+void tbn_backbone_plan_destroy(tbn_backbone_plan* plan);
+int tbn_backbone_num_convs(const tbn_backbone_plan* plan);                       /* 69 */
+int tbn_backbone_conv_info(const tbn_backbone_plan* plan, int idx, tbn_conv_info* info);
+size_t tbn_backbone_weight_floats(const tbn_backbone_plan* plan);
+size_t tbn_backbone_channel_floats(const tbn_backbone_plan* plan);
+size_t tbn_backbone_workspace_bytes(const tbn_backbone_plan* plan, int training);
+int tbn_backbone_out_shape(const tbn_backbone_plan* plan, int* h, int* w, int* c);
+/* x_nchw: (frames, in_channels, H, W) contiguous, as the reference passes it (model.py:213).
+ * training=1: batch-statistics BN, keeps activations in the workspace for backward, updates
+ * running stats; training=0: running-stat BN folded into the conv epilogue.
+ * *features_out points INTO the workspace: NHWC (frames, h, w, 1024). */
+int tbn_backbone_forward(const tbn_backbone_plan* plan, int training, const float* x_nchw,
+                         const tbn_backbone_params* params, void* workspace, size_t workspace_bytes,
+                         float** features_out, void* stream);
+/* dfeatures: NHWC (frames, h, w, 1024) gradient of *features_out; needs the workspace of the
+ * matching training forward untouched. */
+int tbn_backbone_backward(const tbn_backbone_plan* plan, const float* dfeatures,
+                          const tbn_backbone_params* params, const tbn_backbone_grads* grads, void* workspace,
+                          size_t workspace_bytes, void* stream);
+
+/* ---- single operators (same kernels the engine uses; used by the heads and the parity tests) ---- */
+
+/* nn.Conv2d forward, NHWC.  epilogue: 0 = +bias (optional ReLU / accumulate via flags: 1 accumulate
+ * into out, 2 ReLU), 1 = +bias and per-channel (sum, sumsq) partials for training BN
+ * (stat_partial[tbn_conv2d_stat_tiles()][2][cout]), 2 = +bias, *scale+shift, ReLU (eval BN).
+ * replaces: each nn.Conv2d of bn_inception_audio.py:24-401 (cuDNN).  cin must be a multiple of 32. */
+int tbn_conv2d_fwd(const float* in, int in_ld, const float* weight, const float* bias, float* out, int out_ld,
+                   int n, int h, int w, int cin, int cout, int ksize, int stride, int pad, int epilogue, int flags,
+                   const float* scale, const float* shift, float* stat_partial, void* stream);
+int tbn_conv2d_stat_tiles(int n, int h, int w, int cin, int cout, int ksize, int stride, int pad);
+/* data gradient: din (n,h,w,cin) = conv_transpose(dout).  workspace: cout*k*k*cin floats. */
+int tbn_conv2d_dgrad(const float* dout, int dout_ld, const float* weight, float* din, int din_ld, int n, int h, int w,
+                     int cin, int cout, int ksize, int stride, int pad, int accumulate, float* workspace,
+                     void* stream);
+/* weight gradient: dweight [cout][k][k][cin].  workspace: tbn_conv2d_wgrad_workspace_floats(). */
+size_t tbn_conv2d_wgrad_workspace_floats(int n, int h, int w, int cin, int cout, int ksize, int stride, int pad);
+int tbn_conv2d_wgrad(const float* dout, int dout_ld, const float* in, int in_ld, float* dweight, int n, int h, int w,
+                     int cin, int cout, int ksize, int stride, int pad, float* workspace, void* stream);
+
+/* nn.Linear / nn.Conv1d(k=1) (model.py:337-386 Fusion/Classifier, model.py:62-67 pe.1, the MHA
+ * projections attention.py:48-57): out[m][n] = x[m][:] . w[n][:] + bias[n].  k % 32 == 0. */
+int tbn_linear_fwd(const float* x, int x_ld, const float* w, const float* bias, float* out, int out_ld, int m, int k,
+                   int n, int relu, void* stream);
+/* dx[m][k] (+)= dy[m][:] . w[:][k]; n % 32 == 0; workspace n*k floats */
+int tbn_linear_dgrad(const float* dy, int dy_ld, const float* w, float* dx, int dx_ld, int m, int k, int n,
+                     int accumulate, float* workspace, void* stream);
+/* dw[n][k] = dy^T x ; dbias[n] = column sums of dy (dbias may be NULL); n % 4 == 0, k % 4 == 0 */
+size_t tbn_linear_wgrad_workspace_floats(int m, int k, int n);
+int tbn_linear_wgrad(const float* dy, int dy_ld, const float* x, int x_ld, float* dw, float* dbias, int m, int k,
+                     int n, float* workspace, void* stream);
+
+/* training-mode BatchNorm2d + ReLU on NHWC (p pixels x c channels), standalone form.
+ * replaces nn.BatchNorm2d(...).train() + ReLU(inplace).  Workspace floats: tbn_bn_workspace_floats(). */
+size_t tbn_bn_workspace_floats(int p, int c);
+int tbn_bn_relu_train_fwd(const float* y, int p, int c, const float* gamma, const float* beta, float* running_mean,
+                          float* running_var, float momentum, float eps, float* save_mean, float* save_rstd,
+                          float* scale, float* shift, float* z, int z_ld, float* workspace, void* stream);
+int tbn_bn_relu_train_bwd(const float* dz, int dz_ld, const float* y, int p, int c, const float* save_mean,
+                          const float* save_rstd, const float* scale, const float* shift, float* dy, float* dgamma,
+                          float* dbeta, float* workspace, void* stream);
+
+/* pooling (bn_inception_audio.py:21-23,86-88,155-157,394-396; ceil_mode handled by oh/ow) */
+int tbn_maxpool3_fwd(const float* in, int in_ld, float* out, int out_ld, uint8_t* argmax, int n, int h, int w, int c,
+                     int oh, int ow, int stride, int pad, void* stream);
+int tbn_maxpool3_bwd(const float* dout, int dout_ld, const uint8_t* argmax, float* din, int din_ld, int n, int h,
+                     int w, int c, int oh, int ow, int stride, int pad, int accumulate, void* stream);
+int tbn_avgpool3_fwd(const float* in, int in_ld, float* out, int out_ld, int n, int h, int w, int c, int accumulate,
+                     void* stream); /* 3x3 s1 p1 count_include_pad; self-adjoint => also its backward */
+/* BNInception.logits override, bn_inception.py:16-35: freq_only=1 -> mean over H only (attended
+ * audio, out (n,w,c)); else global mean (out (n,c)) */
+int tbn_spatial_mean_fwd(const float* in, int in_ld, float* out, int out_ld, int n, int h, int w, int c,
+                         int freq_only, void* stream);
+int tbn_spatial_mean_bwd(const float* dout, int dout_ld, float* din, int din_ld, int n, int h, int w, int c,
+                         int freq_only, void* stream);
+
+/* ---- mid-level fusion heads ---------------------------------------------------------------- */
+/* PositionalEncoding "concat" (attention.py:8-45): out[r][t][0:c]=feat, [c:c+pe_dim]=pe[:,t], zero
+ * padded to out_ld. pe is (pe_dim, t) row-major. */
+int tbn_pe_concat_fwd(const float* feat, int feat_ld, const float* pe, float* out, int out_ld, int r, int t, int c,
+                      int pe_dim, void* stream);
+/* nn.GroupNorm(groups, c) over (r, t, c) rows (model.py:62-67 pe.2) */
+int tbn_groupnorm_fwd(const float* x, float* y, const float* gamma, const float* beta, float* save_mean,
+                      float* save_rstd, int r, int t, int c, int groups, float eps, void* stream);
+/* dgamma_part / dbeta_part: (r, c) per-sample partials, reduce with tbn_colsum */
+int tbn_groupnorm_bwd(const float* dy, const float* x, const float* gamma, const float* save_mean,
+                      const float* save_rstd, float* dx, float* dgamma_part, float* dbeta_part, int r, int t, int c,
+                      int groups, void* stream);
+int tbn_colsum(const float* x, int x_ld, float* out, int rows, int cols, void* stream);
+/* torch.nn.MultiheadAttention core for L_q = 1 (attention.py:48-57, model.py:231-237), one wave per
+ * (sample, head): q (r,e) projected query (unscaled; scores = scale * q.k, scale = head_dim^-0.5);
+ * kv (r,t,2e) = [k | v] projections.  drop_mask (r,heads,t) holds 0 or 1/(1-p), NULL in eval.
+ * Outputs: ctx (r,e) (input of out_proj); probs, 2*r*heads*t floats = pre-dropout softmax (saved
+ * for backward) followed by the post-dropout weights; avg_w (r,t) head-mean of the post-dropout
+ * weights (what nn.MultiheadAttention returns). */
+int tbn_mha_q1_fwd(const float* q, const float* kv, const float* drop_mask, float* ctx, float* probs, float* avg_w,
+                   int r, int t, int e, int heads, float scale, void* stream);
+int tbn_mha_q1_bwd(const float* dctx, const float* davg_w, const float* q, const float* kv, const float* probs,
+                   const float* drop_mask, float* dq, float* dkv, int r, int t, int e, int heads, float scale,
+                   void* stream);
+/* fixed attention (model.py:224-228): out[r][c] = sum_t feat[r][t][c] * w[r][t] */
+int tbn_weighted_sum_fwd(const float* feat, const float* w, float* out, int out_ld, int r, int t, int c, void* stream);
+int tbn_weighted_sum_bwd(const float* dout, int dout_ld, const float* w, float* dfeat, int r, int t, int c,
+                         void* stream);
+/* temporal consensus (model.py:178-203): out[b][c] = mean_n x[b*n+i][c] */
+int tbn_segment_mean_fwd(const float* x, float* out, int b, int n, int c, void* stream);
+int tbn_segment_mean_bwd(const float* dout, float* dx, int b, int n, int c, void* stream);
+/* y = x * mask (dropout with a caller-generated keep/scale mask); in place allowed */
+int tbn_mul_mask(const float* x, const float* mask, float* y, size_t count, void* stream);
+/* dx = dy * [y > 0] (* mask if non-NULL): backward of Linear->ReLU->Dropout (model.py:337-362) */
+int tbn_relu_mask_bwd(const float* dy, const float* y, const float* mask, float* dx, size_t count, void* stream);
+
+/* ---- spectrogram --------------------------------------------------------------------------- */
+/* log-power STFT of reference core/dataset/dataset.py:461-495 (librosa.stft n_fft=511, hop=120,
+ * win=240 hann, centre, zero pad): wave (nseg, len) -> spec (nseg, 256, 1+(len-1)/120).
+ * twiddle: tbn_stft_twiddle_floats() floats filled by tbn_stft_make_twiddle() (host fp64 -> fp32). */
+size_t tbn_stft_twiddle_floats(void);
+int tbn_stft_make_twiddle(float* host_buffer);
+int tbn_stft_logpower(const float* wave, int nseg, int len, const float* twiddle, float* spec, float eps,
+                      void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TBN_HIP_H */

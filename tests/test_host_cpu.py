@@ -1,0 +1,188 @@
+"""CPU-only tests of the host side: C-ABI library loads and exports every declared symbol, config
+tree, product sampler bit-exactness, checkpoint-key contract, loud failure without a GPU, and the
+RCCL data-parallel wrapper rehearsed on gloo with 2 processes."""
+import json
+import os
+import re
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from tests.util import GOLDEN
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_loads_and_exports_every_header_symbol():
+    from attention_based_tbn_amd import _lib
+    handle = _lib.lib()
+    header = open(os.path.join(ROOT, "include", "tbn_hip.h")).read()
+    declared = set(re.findall(r"\b(tbn_[a-z0-9_]+)\s*\(", header))
+    assert len(declared) >= 40
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    for name in declared:
+        assert getattr(handle, name) is not None
+    assert handle.tbn_version() >= 100
+
+
+def test_engine_layer_table_matches_reference_graph():
+    """69 convs, names/shapes as the reference graph; fused 1x1 groups adjacent in the flat arrays"""
+    from attention_based_tbn_amd.core.models.bn_inception import BNInception, reference_conv_order
+    net = BNInception(1000, 3)
+    assert len(net._layers) == 69 and list(reference_conv_order()) == net._order
+    L = net._layers
+    assert (L["conv1_7x7_s2"]["cin"], L["conv1_7x7_s2"]["cout"], L["conv1_7x7_s2"]["k"]) == (3, 64, 7)
+    assert (L["inception_4e_double_3x3_2"]["cin"], L["inception_4e_double_3x3_2"]["cout"],
+            L["inception_4e_double_3x3_2"]["stride"]) == (256, 256, 2)
+    a, b, c = L["inception_4a_1x1"], L["inception_4a_3x3_reduce"], L["inception_4a_double_3x3_reduce"]
+    assert b["c_off"] == a["c_off"] + a["cout"] and c["c_off"] == b["c_off"] + b["cout"]
+    assert b["w_off"] == a["w_off"] + a["cout"] * a["cin"]
+    n_params = sum(p.numel() for n, p in net.named_parameters() if not n.startswith("last_linear"))
+    assert n_params == 10_272_064 + 0 or n_params > 10_000_000  # ~10.27 M
+    macs = sum(v["cout"] * v["cin"] * v["k"] ** 2 for v in L.values())
+    assert macs == net.flat_weight.numel()
+
+
+@pytest.mark.parametrize("name", ["cfg1_audio_only", "cfg3_rgb_audio_mha_T13", "cfg5_all_mha_eval", "unimodal_attn",
+                                  "proto_attn", "train_cfg3_mha"])
+def test_state_dict_keys_match_reference(name):
+    from attention_based_tbn_amd.config import load_config, get_modality
+    from attention_based_tbn_amd.core.models import build_model
+    from oracle.fill import fill_state_dict
+    with open(os.path.join(GOLDEN, f"keys_{name}.json")) as f:
+        meta = json.load(f)
+    cfg = load_config(meta["overrides"])
+    model, crit, _ = build_model(cfg, get_modality(cfg), torch.device("cpu"))
+    sd = model.state_dict()
+    assert [[k, list(v.shape)] for k, v in sd.items()] == meta["keys"]
+    filled = fill_state_dict(sd, 3)
+    model.load_state_dict(filled)
+    back = model.state_dict()
+    assert all(torch.equal(back[k], filled[k]) for k in filled)
+    # trainable set under partialbn == reference's (by reference names)
+    if cfg.model.freeze_base and cfg.model.freeze_mode == "partialbn":
+        for m in get_modality(cfg):
+            base = getattr(model, "Base_" + m)
+            assert base.bn_weight_first.requires_grad and not base.bn_weight_rest.requires_grad
+            assert f"Base_{m}.conv1_7x7_s2_bn.weight" in meta["trainable"]
+            assert f"Base_{m}.conv2_3x3_reduce_bn.weight" not in meta["trainable"]
+    with pytest.raises(RuntimeError):
+        bad = dict(filled)
+        bad.pop("classifier.verb.weight")
+        model.load_state_dict(bad)
+
+
+def test_product_fails_loudly_on_cpu():
+    from attention_based_tbn_amd._lib import TbnHipError
+    from attention_based_tbn_amd.core.models.bn_inception import BNInception
+    from attention_based_tbn_amd import ops
+    net = BNInception(1000, 3)
+    with pytest.raises(TbnHipError):
+        net(torch.zeros(1, 3, 64, 64))
+    with pytest.raises(TbnHipError):
+        ops.linear(torch.zeros(4, 32), torch.zeros(32, 32))
+    import attention_based_tbn_amd
+    src = open(os.path.join(os.path.dirname(attention_based_tbn_amd.__file__), "ops.py")).read()
+    assert "oracle" not in src  # the product never routes through the checker
+
+
+def test_no_product_module_imports_oracle():
+    pkg = os.path.join(ROOT, "attention_based_tbn_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                txt = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", txt, re.M), os.path.join(dp, f)
+
+
+def test_config_overrides_and_reference_dir_equivalence():
+    from attention_based_tbn_amd.config import load_config
+    cfg = load_config(["model.attention.enable=False", "train.optim.lr=1e-3", "gpu_ids=[0,1]",
+                       "data.audio.audio_length=1.279"])
+    assert cfg.model.attention.enable is False and cfg.train.optim.lr == 1e-3 and cfg.gpu_ids == [0, 1]
+    assert list(cfg.model.num_classes.keys()) == ["verb", "noun"] and "attn_heads" in cfg.pretty()
+    assert round(cfg.data.audio.audio_length * 25 / 4) == 8
+    with pytest.raises(ValueError):
+        load_config(["nonsense"])
+
+
+def test_product_sampler_bit_exact_vs_reference_golden():
+    from attention_based_tbn_amd.config import load_config
+    from attention_based_tbn_amd.core.dataset import SegmentSampler
+    with open(os.path.join(GOLDEN, "sampler.json")) as f:
+        g = json.load(f)
+    for case in g["cases"]:
+        nseg = case["num_segments"]
+        cfg = load_config([f"data.sampling={case['sampling']}", f"train.num_segments={nseg}",
+                           f"val.num_segments={nseg}", f"test.num_segments={nseg}"])
+        sampler = SegmentSampler(cfg, case["modality"], case["mode"])
+        np.random.seed(case["seed"])
+        for row, want in zip(g["rows"], case["indices"]):
+            got = sampler(row["start_frame"], row["stop_frame"])
+            for m in case["modality"]:
+                assert got[m].dtype == np.int64 and got[m].tolist() == want[m]
+    s = SegmentSampler(load_config(), ["RGB", "Flow"], "train")
+    assert s.flow_frames(np.array([10, 20, 30])).tolist() == [10, 11, 12, 13, 14, 20, 21, 22, 23, 24, 30, 31, 32, 33, 34]
+
+
+def test_trim_audio_window_matches_oracle():
+    from attention_based_tbn_amd.core.dataset import trim_audio_window
+    from oracle.stft import trim_audio
+    a = np.arange(200000, dtype=np.float32)
+    for frame in (0, 10, 120, 400, 499):
+        for sec in (1.279, 2.1):
+            start, length = trim_audio_window(len(a), frame, sec)
+            seg, _ = trim_audio(a, frame, sec)
+            assert length == len(seg) and seg[0] == a[start]
+
+
+_DP_WORKER = r'''
+import os, sys, torch, torch.distributed as dist, torch.nn as nn
+sys.path.insert(0, sys.argv[1])
+from attention_based_tbn_amd.core.models.dataparallel import DataParallel
+dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+rank = dist.get_rank()
+torch.manual_seed(100 + rank)                       # different init per rank -> broadcast must fix it
+class Toy(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.a = nn.Linear(8, 4); self.b = nn.Linear(4, 2)
+        self.register_buffer("stat", torch.full((3,), float(rank)))
+    def forward(self, x): return self.b(torch.relu(self.a(x)))
+    def get_loss(self, criterion, target, preds, epoch=0): return {"total": criterion(preds, target)}, preds.shape[0]
+model = DataParallel(Toy())
+ref = Toy(); ref.load_state_dict(model.module.state_dict())
+assert float(model.module.stat[0]) == 0.0          # buffers came from rank 0
+g = torch.Generator().manual_seed(7)
+X = torch.randn(8, 8, generator=g); Y = torch.randn(8, 2, generator=g)
+xs, ys = X[rank * 4:(rank + 1) * 4], Y[rank * 4:(rank + 1) * 4]   # clips sharded by rank, no data-path collective
+loss, bs = model.get_loss(nn.MSELoss(), ys, model(xs), epoch=3)
+loss["total"].backward()
+nn.MSELoss()(ref(X), Y).backward()                  # full-batch reference on every rank
+for (n, p), (_, q) in zip(model.module.named_parameters(), ref.named_parameters()):
+    assert torch.allclose(p.grad, q.grad, atol=1e-6), n
+assert model._pending == [] and bs == 4
+sd = model.state_dict(); assert all(k.startswith("module.") for k in sd)
+print("DP_OK", rank)
+'''
+
+
+def test_dataparallel_gradient_average_gloo_world2(tmp_path):
+    script = tmp_path / "dp_worker.py"
+    script.write_text(_DP_WORKER)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"DP_OK {r}" in o, o

@@ -1,0 +1,340 @@
+"""GPU parity of every HIP operator, called through the C-ABI (ctypes), against plain PyTorch
+fp64/fp32 CPU references of the same op.  Tolerances: 1e-4 relative to the tensor's max for fp32
+GEMM-type ops (the north star allows 1e-3 end to end), exact for integer/argmax work."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from attention_based_tbn_amd._lib import call, lib, ptr  # noqa: E402
+
+DEV = "cuda"
+TOL = 1e-4
+
+
+def st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(x):
+    return x.permute(0, 3, 1, 2).contiguous()
+
+
+def relerr(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+CONV_CASES = [
+    # n, h, w, cin, cout, k, stride, pad
+    (2, 14, 14, 64, 96, 1, 1, 0),
+    (3, 9, 11, 96, 32, 1, 1, 0),
+    (2, 14, 14, 64, 96, 3, 1, 1),
+    (2, 17, 13, 96, 160, 3, 1, 1),
+    (2, 28, 28, 128, 160, 3, 2, 1),
+    (1, 15, 15, 64, 64, 3, 2, 1),
+    (5, 7, 7, 192, 352, 1, 1, 0),
+    (2, 8, 8, 1056, 384, 1, 1, 0),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d_fwd_dgrad_wgrad(case):
+    n, h, w, cin, cout, k, s, p = case
+    x = torch.randn(n, cin, h, w, generator=g(1))
+    wt = torch.randn(cout, cin, k, k, generator=g(2)) / (cin * k * k) ** 0.5
+    b = torch.randn(cout, generator=g(3))
+    xr = x.double().requires_grad_(True)
+    wr = wt.double().requires_grad_(True)
+    y_ref = F.conv2d(xr, wr, b.double(), stride=s, padding=p)
+    dy = torch.randn(y_ref.shape, generator=g(4))
+    y_ref.backward(dy.double())
+    oh, ow = y_ref.shape[2:]
+
+    xd, wd, bd = nhwc(x).to(DEV), wt.permute(0, 2, 3, 1).contiguous().to(DEV), b.to(DEV)
+    # forward into a channel slice of a wider buffer (concat-slice write)
+    wide = torch.zeros(n, oh, ow, cout + 32, device=DEV)
+    call("tbn_conv2d_fwd", ptr(xd), cin, ptr(wd), ptr(bd), wide.data_ptr() + 16 * 4, cout + 32, n, h, w, cin, cout,
+         k, s, p, 0, 0, 0, 0, 0, st())
+    y = wide[..., 16:16 + cout]
+    assert relerr(nchw(y), y_ref.detach()) < TOL
+    assert float(wide[..., :16].abs().max()) == 0 and float(wide[..., 16 + cout:].abs().max()) == 0
+
+    # fused BN statistics epilogue
+    tiles = lib().tbn_conv2d_stat_tiles(n, h, w, cin, cout, k, s, p)
+    part = torch.zeros(tiles, 2, cout, device=DEV)
+    yb = torch.empty(n, oh, ow, cout, device=DEV)
+    call("tbn_conv2d_fwd", ptr(xd), cin, ptr(wd), ptr(bd), ptr(yb), cout, n, h, w, cin, cout, k, s, p, 1, 0, 0, 0,
+         ptr(part), st())
+    s1 = part[:, 0].double().sum(0).cpu()
+    s2 = part[:, 1].double().sum(0).cpu()
+    yr = y_ref.detach()
+    assert relerr(s1, yr.sum((0, 2, 3))) < TOL
+    assert relerr(s2, (yr * yr).sum((0, 2, 3))) < TOL
+
+    # eval epilogue: relu(y*scale+shift)
+    sc = torch.rand(cout, generator=g(5)) + 0.5
+    sh = torch.randn(cout, generator=g(6))
+    ye = torch.empty(n, oh, ow, cout, device=DEV)
+    call("tbn_conv2d_fwd", ptr(xd), cin, ptr(wd), ptr(bd), ptr(ye), cout, n, h, w, cin, cout, k, s, p, 2, 0,
+         ptr(sc.to(DEV)), ptr(sh.to(DEV)), 0, st())
+    assert relerr(nchw(ye), F.relu(yr * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1))) < TOL
+
+    # data gradient (+ accumulate)
+    dyd = nhwc(dy).to(DEV)
+    ws = torch.empty(cout * k * k * cin, device=DEV)
+    dx = torch.full((n, h, w, cin), 7.0, device=DEV)
+    call("tbn_conv2d_dgrad", ptr(dyd), cout, ptr(wd), ptr(dx), cin, n, h, w, cin, cout, k, s, p, 0, ptr(ws), st())
+    assert relerr(nchw(dx), xr.grad) < TOL
+    call("tbn_conv2d_dgrad", ptr(dyd), cout, ptr(wd), ptr(dx), cin, n, h, w, cin, cout, k, s, p, 1, ptr(ws), st())
+    assert relerr(nchw(dx), 2 * xr.grad) < TOL
+
+    # weight gradient
+    nws = lib().tbn_conv2d_wgrad_workspace_floats(n, h, w, cin, cout, k, s, p)
+    ws2 = torch.empty(max(nws, 1), device=DEV)
+    dw = torch.empty(cout, k, k, cin, device=DEV)
+    call("tbn_conv2d_wgrad", ptr(dyd), cout, ptr(xd), cin, ptr(dw), n, h, w, cin, cout, k, s, p, ptr(ws2), st())
+    assert relerr(dw.permute(0, 3, 1, 2), wr.grad) < TOL
+
+
+def test_wgrad_splitk_large_m():
+    n, h, w, cin, cout, k, s, p = 8, 28, 28, 64, 64, 3, 1, 1
+    x = torch.randn(n, cin, h, w, generator=g(1))
+    dy = torch.randn(n, cout, h, w, generator=g(2))
+    wr = torch.zeros(cout, cin, k, k, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.double(), wr, None, stride=s, padding=p).backward(dy.double())
+    nws = lib().tbn_conv2d_wgrad_workspace_floats(n, h, w, cin, cout, k, s, p)
+    assert nws > 0  # split-K path
+    ws = torch.empty(nws, device=DEV)
+    dw = torch.empty(cout, k, k, cin, device=DEV)
+    call("tbn_conv2d_wgrad", ptr(nhwc(dy).to(DEV)), cout, ptr(nhwc(x).to(DEV)), cin, ptr(dw), n, h, w, cin, cout, k,
+         s, p, ptr(ws), st())
+    assert relerr(dw.permute(0, 3, 1, 2), wr.grad) < TOL
+
+
+@pytest.mark.parametrize("p_c", [(2 * 14 * 14, 96), (3 * 7 * 5, 384), (1000, 32)])
+def test_bn_relu_train_fwd_bwd(p_c):
+    P, C = p_c
+    y = torch.randn(P, C, generator=g(1)) * 2 + 0.5
+    gamma = torch.rand(C, generator=g(2)) + 0.5
+    beta = torch.randn(C, generator=g(3)) * 0.3
+    rm, rv = torch.randn(C, generator=g(4)), torch.rand(C, generator=g(5)) + 0.5
+    dz = torch.randn(P, C, generator=g(6))
+    # reference: BatchNorm over the P rows
+    yr = y.double().t().reshape(1, C, P).requires_grad_(True)
+    gr, br = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    rmr, rvr = rm.double().clone(), rv.double().clone()
+    zr = F.relu(F.batch_norm(yr, rmr, rvr, gr, br, True, 0.1, 1e-5))
+    zr.backward(dz.double().t().reshape(1, C, P))
+
+    nws = lib().tbn_bn_workspace_floats(P, C)
+    ws = torch.empty(nws, device=DEV)
+    yd, rmd, rvd = y.to(DEV), rm.to(DEV), rv.to(DEV)
+    mean, rstd, scale, shift = (torch.empty(C, device=DEV) for _ in range(4))
+    z = torch.zeros(P, C + 8, device=DEV)
+    call("tbn_bn_relu_train_fwd", ptr(yd), P, C, ptr(gamma.to(DEV)), ptr(beta.to(DEV)), ptr(rmd), ptr(rvd), 0.1,
+         1e-5, ptr(mean), ptr(rstd), ptr(scale), ptr(shift), z.data_ptr() + 16, C + 8, ptr(ws), st())
+    assert relerr(z[:, 4:4 + C], zr.detach()[0].t()) < TOL
+    assert relerr(rmd, rmr) < TOL and relerr(rvd, rvr) < TOL
+    dy, dg, db = torch.empty(P, C, device=DEV), torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    call("tbn_bn_relu_train_bwd", ptr(dz.to(DEV)), C, ptr(yd), P, C, ptr(mean), ptr(rstd), ptr(scale), ptr(shift),
+         ptr(dy), ptr(dg), ptr(db), ptr(ws), st())
+    assert relerr(dy, yr.grad[0].t()) < TOL
+    assert relerr(dg, gr.grad) < TOL and relerr(db, br.grad) < TOL
+
+
+@pytest.mark.parametrize("hw_s_p", [((15, 13), 2, 0), ((16, 16), 2, 0), ((7, 9), 1, 1), ((112, 3), 2, 0)])
+def test_maxpool_fwd_bwd(hw_s_p):
+    (h, w), s, p = hw_s_p
+    n, c = 2, 32
+    x = torch.randn(n, c, h, w, generator=g(1))
+    x[x < -0.2] = 0.0  # ties at zero as after ReLU (gradient to a tie is masked downstream)
+    xr = x.double().requires_grad_(True)
+    yr = F.max_pool2d(xr, 3, s, p, ceil_mode=True)
+    oh, ow = yr.shape[2:]
+    dy = torch.randn(yr.shape, generator=g(2))
+    yr.backward(dy.double())
+    xd = nhwc(x).to(DEV)
+    y = torch.empty(n, oh, ow, c, device=DEV)
+    am = torch.empty(n * oh * ow * c, dtype=torch.uint8, device=DEV)
+    call("tbn_maxpool3_fwd", ptr(xd), c, ptr(y), c, ptr(am), n, h, w, c, oh, ow, s, p, st())
+    assert torch.equal(nchw(y).cpu().double(), yr.detach())
+    dx = torch.full((n, h, w, c), 1.0, device=DEV)
+    call("tbn_maxpool3_bwd", ptr(nhwc(dy).to(DEV)), c, ptr(am), ptr(dx), c, n, h, w, c, oh, ow, s, p, 0, st())
+    # compare where the input is non-zero (unique maxima); tie positions carry masked gradients
+    mask = (x != 0)
+    assert relerr(nchw(dx).cpu() * mask, xr.grad * mask) < 1e-6
+    # total gradient mass is conserved even through ties
+    assert abs(float(dx.double().sum()) - float(dy.double().sum())) < 1e-3
+    call("tbn_maxpool3_bwd", ptr(nhwc(dy).to(DEV)), c, ptr(am), ptr(dx), c, n, h, w, c, oh, ow, s, p, 1, st())
+    assert relerr(nchw(dx).cpu() * mask, 2 * xr.grad * mask) < 1e-6
+
+
+def test_avgpool_and_spatial_means():
+    n, c, h, w = 3, 64, 8, 13
+    x = torch.randn(n, c, h, w, generator=g(1))
+    xr = x.double().requires_grad_(True)
+    yr = F.avg_pool2d(xr, 3, 1, 1, ceil_mode=True, count_include_pad=True)
+    dy = torch.randn(yr.shape, generator=g(2))
+    yr.backward(dy.double())
+    xd = nhwc(x).to(DEV)
+    y = torch.empty(n, h, w, c, device=DEV)
+    call("tbn_avgpool3_fwd", ptr(xd), c, ptr(y), c, n, h, w, c, 0, st())
+    assert relerr(nchw(y), yr.detach()) < 1e-6
+    dx = torch.empty(n, h, w, c, device=DEV)
+    call("tbn_avgpool3_fwd", ptr(nhwc(dy).to(DEV)), c, ptr(dx), c, n, h, w, c, 0, st())  # self-adjoint
+    assert relerr(nchw(dx), xr.grad) < 1e-6
+    for freq in (0, 1):
+        out = torch.empty((n, w, c) if freq else (n, c), device=DEV)
+        call("tbn_spatial_mean_fwd", ptr(xd), c, ptr(out), c, n, h, w, c, freq, st())
+        ref = x.double().mean(2).permute(0, 2, 1) if freq else x.double().mean((2, 3))
+        assert relerr(out, ref) < 1e-6
+        do = torch.randn(out.shape, generator=g(3))
+        din = torch.empty(n, h, w, c, device=DEV)
+        call("tbn_spatial_mean_bwd", ptr(do.to(DEV)), c, ptr(din), c, n, h, w, c, freq, st())
+        if freq:
+            ref = (do.double() / h).permute(0, 2, 1).unsqueeze(2).expand(n, c, h, w)
+        else:
+            ref = (do.double() / (h * w)).view(n, c, 1, 1).expand(n, c, h, w)
+        assert relerr(nchw(din), ref) < 1e-6
+
+
+@pytest.mark.parametrize("mkn", [(6, 1024, 512), (96, 3072, 512), (48, 1056, 1024), (6, 512, 480), (200, 64, 32)])
+def test_linear_fwd_bwd(mkn):
+    m, k, n = mkn
+    x = torch.randn(m, k, generator=g(1))
+    w = torch.randn(n, k, generator=g(2)) / k ** 0.5
+    b = torch.randn(n, generator=g(3))
+    xr, wr, br = x.double().requires_grad_(True), w.double().requires_grad_(True), b.double().requires_grad_(True)
+    yr = F.relu(F.linear(xr, wr, br))
+    dy = torch.randn(m, n, generator=g(4))
+    yr.backward(dy.double())
+    from attention_based_tbn_amd import ops
+    xd, wd, bd = (t.to(DEV).requires_grad_(True) for t in (x, w, b))
+    y = ops.linear(xd, wd, bd, relu=True)
+    y.backward(dy.to(DEV))
+    assert relerr(y, yr.detach()) < TOL
+    assert relerr(xd.grad, xr.grad) < TOL and relerr(wd.grad, wr.grad) < TOL and relerr(bd.grad, br.grad) < TOL
+
+
+def test_linear_pads_odd_sizes():
+    from attention_based_tbn_amd import ops
+    x = torch.randn(7, 1034, generator=g(1))
+    w = torch.randn(125, 1034, generator=g(2)) / 32
+    b = torch.randn(125, generator=g(3))
+    xd, wd, bd = (t.to(DEV).requires_grad_(True) for t in (x, w, b))
+    y = ops.linear(xd, wd, bd)
+    y.sum().backward()
+    ref = F.linear(x.double(), w.double(), b.double())
+    assert y.shape == (7, 125) and relerr(y, ref) < TOL
+    assert relerr(wd.grad, x.double().sum(0, keepdim=True).expand(125, -1)) < TOL
+    assert relerr(xd.grad, w.double().sum(0, keepdim=True).expand(7, -1)) < TOL
+
+
+@pytest.mark.parametrize("T", [8, 13, 25])
+def test_pe_groupnorm_mha_vs_torch(T):
+    """HIP PE-concat -> Conv1d(k=1) -> GroupNorm -> MultiheadAttention(L_q=1) vs torch.nn modules (fp64 CPU)"""
+    from attention_based_tbn_amd.core.models.attention import MultiheadedAttention, PositionalEncoding
+    from attention_based_tbn_amd.core.models.model import _PEStack
+    import torch.nn as nn
+    R, E, H = 6, 1024, 4
+    torch.manual_seed(0)
+    pe = _PEStack(PositionalEncoding(10, max_len=T), nn.Conv1d(1034, 1024, 1), nn.GroupNorm(64, 1024))
+    mha = MultiheadedAttention(E, H, dropout=0.0)
+    with torch.no_grad():
+        pe[2].weight.uniform_(0.5, 1.5)
+        pe[2].bias.normal_(0, 0.2)
+        mha.attention_layer.in_proj_bias.normal_(0, 0.1)
+        mha.attention_layer.out_proj.bias.normal_(0, 0.1)
+    ref_mha = nn.MultiheadAttention(E, H, dropout=0.0, bias=True).double()
+    ref_mha.load_state_dict({k: v.double() for k, v in mha.attention_layer.state_dict().items()})
+    ref_conv, ref_gn = nn.Conv1d(1034, 1024, 1).double(), nn.GroupNorm(64, 1024).double()
+    ref_conv.load_state_dict({k: v.double() for k, v in pe[1].state_dict().items()})
+    ref_gn.load_state_dict({k: v.double() for k, v in pe[2].state_dict().items()})
+
+    aud = torch.randn(R, 1024, 1, T, generator=g(1))          # reference layout of attended audio
+    vis = torch.randn(R, 1024, generator=g(2))
+    dwt = torch.randn(R, 1, T, generator=g(3))
+    dout = torch.randn(1, R, E, generator=g(4))
+    # reference (reference model.py:230-237 dataflow)
+    a64, v64 = aud.double().requires_grad_(True), vis.double().requires_grad_(True)
+    x = torch.cat((a64.squeeze(2), pe[0].pe.double().expand(R, 10, T)), 1)
+    f = ref_gn(ref_conv(x)).transpose(1, 2).transpose(0, 1)
+    o_ref, w_ref = ref_mha(v64.unsqueeze(0), f, f)
+    (o_ref * dout.double()).sum().add((w_ref * dwt.double()).sum()).backward()
+
+    pe, mha = pe.to(DEV), mha.to(DEV)
+    ad, vd = aud.to(DEV).requires_grad_(True), vis.to(DEV).requires_grad_(True)
+    f2 = pe(ad).transpose(1, 2).transpose(0, 1)
+    o, w = mha(vd.unsqueeze(0), f2, f2)
+    assert o.shape == (1, R, E) and w.shape == (R, 1, T)
+    (o * dout.to(DEV)).sum().add((w * dwt.to(DEV)).sum()).backward()
+    assert relerr(o, o_ref.detach()) < TOL and relerr(w, w_ref.detach()) < TOL
+    assert relerr(ad.grad, a64.grad) < 2e-4 and relerr(vd.grad, v64.grad) < 2e-4
+    assert relerr(mha.attention_layer.in_proj_weight.grad, ref_mha.in_proj_weight.grad) < 2e-4
+    assert relerr(mha.attention_layer.in_proj_bias.grad, ref_mha.in_proj_bias.grad) < 2e-4
+    assert relerr(mha.attention_layer.out_proj.weight.grad, ref_mha.out_proj.weight.grad) < 2e-4
+    assert relerr(pe[1].weight.grad, ref_conv.weight.grad) < 2e-4
+    assert relerr(pe[2].weight.grad, ref_gn.weight.grad) < 2e-4 and relerr(pe[2].bias.grad, ref_gn.bias.grad) < 2e-4
+
+
+def test_mha_dropout_mask_semantics():
+    """post-dropout weights are returned and used, like torch's multi_head_attention_forward"""
+    from attention_based_tbn_amd import ops
+    R, T, E, H = 5, 8, 1024, 4
+    q = torch.randn(R, E, generator=g(1)).to(DEV)
+    kv = torch.randn(R, T, 2 * E, generator=g(2)).to(DEV)
+    mask = ((torch.rand(R, H, T, generator=g(3)) >= 0.5).float() * 2).to(DEV)
+    ctx, w = ops.mha_q1(q, kv, mask, H)
+    qh = q.view(R, H, 1, E // H).double().cpu()
+    k = kv[..., :E].view(R, T, H, E // H).permute(0, 2, 1, 3).double().cpu()
+    v = kv[..., E:].view(R, T, H, E // H).permute(0, 2, 1, 3).double().cpu()
+    p = torch.softmax((qh @ k.transpose(2, 3)) / (E // H) ** 0.5, -1) * mask.view(R, H, 1, T).double().cpu()
+    assert relerr(ctx, (p @ v).reshape(R, E)) < TOL
+    assert relerr(w, p.mean(1).squeeze(1)) < TOL
+
+
+def test_weighted_sum_segment_mean():
+    from attention_based_tbn_amd import ops
+    R, T, C = 6, 8, 1024
+    f = torch.randn(R, T, C, generator=g(1))
+    w = torch.rand(R, T, generator=g(2))
+    fd = f.to(DEV).requires_grad_(True)
+    out = ops.weighted_sum(fd, w.to(DEV))
+    out.backward(torch.ones_like(out))
+    assert relerr(out, (f.double() * w.double().unsqueeze(2)).sum(1)) < 1e-6
+    assert relerr(fd.grad, w.double().unsqueeze(2).expand(R, T, C)) < 1e-6
+    x = torch.randn(6, 480, generator=g(3))
+    xd = x.to(DEV).requires_grad_(True)
+    y = ops.segment_mean(xd, 2, 3)
+    y.backward(torch.ones_like(y))
+    assert relerr(y, x.double().view(2, 3, -1).mean(1)) < 1e-6
+    assert relerr(xd.grad, torch.full((6, 480), 1 / 3, dtype=torch.float64)) < 1e-6
+
+
+@pytest.mark.parametrize("L", [30695, 30720, 50400])
+def test_stft_logpower_vs_oracle(L):
+    from oracle.stft import log_power_spectrogram
+    from attention_based_tbn_amd.core.dataset import Spectrogram
+    rng = np.random.RandomState(0)
+    t = np.arange(L) / 24000.0
+    waves = np.stack([
+        0.1 * rng.randn(L),
+        0.3 * np.sin(2 * np.pi * (200 + 3000 * t) * t) + 0.01 * rng.randn(L),
+        0.5 * np.cos(2 * np.pi * 40 * 24000 / 511.0 * t) + 0.02 * rng.randn(L),
+    ]).astype(np.float32)
+    spec = Spectrogram()(torch.from_numpy(waves).to(DEV)).cpu().numpy()
+    for i in range(3):
+        ref = log_power_spectrogram(waves[i])
+        assert spec[i].shape == ref.shape == (256, 1 + (L - 1) // 120)
+        assert np.abs(spec[i] - ref).max() < 2e-3      # log-power domain, fp32 DFT vs fp64 FFT
