@@ -86,8 +86,9 @@ def test_conv2d_fwd_dgrad_wgrad(case):
     sc = torch.rand(cout, generator=g(5)) + 0.5
     sh = torch.randn(cout, generator=g(6))
     ye = torch.empty(n, oh, ow, cout, device=DEV)
+    scd, shd = sc.to(DEV), sh.to(DEV)   # keep references: ptr() of a temporary dangles
     call("tbn_conv2d_fwd", ptr(xd), cin, ptr(wd), ptr(bd), ptr(ye), cout, n, h, w, cin, cout, k, s, p, 2, 0,
-         ptr(sc.to(DEV)), ptr(sh.to(DEV)), 0, st())
+         ptr(scd), ptr(shd), 0, st())
     assert relerr(nchw(ye), F.relu(yr * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1))) < TOL
 
     # data gradient (+ accumulate)
@@ -117,8 +118,8 @@ def test_wgrad_splitk_large_m():
     assert nws > 0  # split-K path
     ws = torch.empty(nws, device=DEV)
     dw = torch.empty(cout, k, k, cin, device=DEV)
-    call("tbn_conv2d_wgrad", ptr(nhwc(dy).to(DEV)), cout, ptr(nhwc(x).to(DEV)), cin, ptr(dw), n, h, w, cin, cout, k,
-         s, p, ptr(ws), st())
+    dyd, xd = nhwc(dy).to(DEV), nhwc(x).to(DEV)
+    call("tbn_conv2d_wgrad", ptr(dyd), cout, ptr(xd), cin, ptr(dw), n, h, w, cin, cout, k, s, p, ptr(ws), st())
     assert relerr(dw.permute(0, 3, 1, 2), wr.grad) < TOL
 
 
@@ -142,12 +143,13 @@ def test_bn_relu_train_fwd_bwd(p_c):
     yd, rmd, rvd = y.to(DEV), rm.to(DEV), rv.to(DEV)
     mean, rstd, scale, shift = (torch.empty(C, device=DEV) for _ in range(4))
     z = torch.zeros(P, C + 8, device=DEV)
-    call("tbn_bn_relu_train_fwd", ptr(yd), P, C, ptr(gamma.to(DEV)), ptr(beta.to(DEV)), ptr(rmd), ptr(rvd), 0.1,
+    gd, btd, dzd = gamma.to(DEV), beta.to(DEV), dz.to(DEV)
+    call("tbn_bn_relu_train_fwd", ptr(yd), P, C, ptr(gd), ptr(btd), ptr(rmd), ptr(rvd), 0.1,
          1e-5, ptr(mean), ptr(rstd), ptr(scale), ptr(shift), z.data_ptr() + 16, C + 8, ptr(ws), st())
     assert relerr(z[:, 4:4 + C], zr.detach()[0].t()) < TOL
     assert relerr(rmd, rmr) < TOL and relerr(rvd, rvr) < TOL
     dy, dg, db = torch.empty(P, C, device=DEV), torch.empty(C, device=DEV), torch.empty(C, device=DEV)
-    call("tbn_bn_relu_train_bwd", ptr(dz.to(DEV)), C, ptr(yd), P, C, ptr(mean), ptr(rstd), ptr(scale), ptr(shift),
+    call("tbn_bn_relu_train_bwd", ptr(dzd), C, ptr(yd), P, C, ptr(mean), ptr(rstd), ptr(scale), ptr(shift),
          ptr(dy), ptr(dg), ptr(db), ptr(ws), st())
     assert relerr(dy, yr.grad[0].t()) < TOL
     assert relerr(dg, gr.grad) < TOL and relerr(db, br.grad) < TOL
@@ -170,13 +172,14 @@ def test_maxpool_fwd_bwd(hw_s_p):
     call("tbn_maxpool3_fwd", ptr(xd), c, ptr(y), c, ptr(am), n, h, w, c, oh, ow, s, p, st())
     assert torch.equal(nchw(y).cpu().double(), yr.detach())
     dx = torch.full((n, h, w, c), 1.0, device=DEV)
-    call("tbn_maxpool3_bwd", ptr(nhwc(dy).to(DEV)), c, ptr(am), ptr(dx), c, n, h, w, c, oh, ow, s, p, 0, st())
+    dyd = nhwc(dy).to(DEV)
+    call("tbn_maxpool3_bwd", ptr(dyd), c, ptr(am), ptr(dx), c, n, h, w, c, oh, ow, s, p, 0, st())
     # compare where the input is non-zero (unique maxima); tie positions carry masked gradients
     mask = (x != 0)
     assert relerr(nchw(dx).cpu() * mask, xr.grad * mask) < 1e-6
     # total gradient mass is conserved even through ties
     assert abs(float(dx.double().sum()) - float(dy.double().sum())) < 1e-3
-    call("tbn_maxpool3_bwd", ptr(nhwc(dy).to(DEV)), c, ptr(am), ptr(dx), c, n, h, w, c, oh, ow, s, p, 1, st())
+    call("tbn_maxpool3_bwd", ptr(dyd), c, ptr(am), ptr(dx), c, n, h, w, c, oh, ow, s, p, 1, st())
     assert relerr(nchw(dx).cpu() * mask, 2 * xr.grad * mask) < 1e-6
 
 
@@ -192,7 +195,8 @@ def test_avgpool_and_spatial_means():
     call("tbn_avgpool3_fwd", ptr(xd), c, ptr(y), c, n, h, w, c, 0, st())
     assert relerr(nchw(y), yr.detach()) < 1e-6
     dx = torch.empty(n, h, w, c, device=DEV)
-    call("tbn_avgpool3_fwd", ptr(nhwc(dy).to(DEV)), c, ptr(dx), c, n, h, w, c, 0, st())  # self-adjoint
+    dyd = nhwc(dy).to(DEV)
+    call("tbn_avgpool3_fwd", ptr(dyd), c, ptr(dx), c, n, h, w, c, 0, st())  # self-adjoint
     assert relerr(nchw(dx), xr.grad) < 1e-6
     for freq in (0, 1):
         out = torch.empty((n, w, c) if freq else (n, c), device=DEV)
@@ -201,7 +205,8 @@ def test_avgpool_and_spatial_means():
         assert relerr(out, ref) < 1e-6
         do = torch.randn(out.shape, generator=g(3))
         din = torch.empty(n, h, w, c, device=DEV)
-        call("tbn_spatial_mean_bwd", ptr(do.to(DEV)), c, ptr(din), c, n, h, w, c, freq, st())
+        dod = do.to(DEV)
+        call("tbn_spatial_mean_bwd", ptr(dod), c, ptr(din), c, n, h, w, c, freq, st())
         if freq:
             ref = (do.double() / h).permute(0, 2, 1).unsqueeze(2).expand(n, c, h, w)
         else:
