@@ -38,6 +38,8 @@ SIGNATURES = {
     "tbn_backbone_channel_floats": (c_sz, [C.c_void_p]),
     "tbn_backbone_workspace_bytes": (c_sz, [C.c_void_p, c_i]),
     "tbn_backbone_out_shape": (c_i, [C.c_void_p, C.POINTER(c_i), C.POINTER(c_i), C.POINTER(c_i)]),
+    "tbn_backbone_tensor_info": (c_i, [C.c_void_p, C.c_char_p, c_i, C.POINTER(C.c_long), C.POINTER(c_i),
+                                       C.POINTER(c_i), C.POINTER(c_i)]),
     "tbn_backbone_forward": (c_i, [C.c_void_p, c_i, c_fp, C.POINTER(BackboneParams), c_fp, c_sz,
                                    C.POINTER(C.c_void_p), c_fp]),
     "tbn_backbone_backward": (c_i, [C.c_void_p, c_fp, C.POINTER(BackboneParams), C.POINTER(BackboneGrads), c_fp,

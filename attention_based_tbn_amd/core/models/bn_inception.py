@@ -82,8 +82,8 @@ class _BackboneFn(torch.autograd.Function):
     def forward(ctx, x, weight, bias, g0, g1, b0, b1, module, freq_only):
         plan = module._plan(x.shape[0], x.shape[2], x.shape[3])
         training = module.training
-        need_grad = training and torch.is_grad_enabled() and any(
-            t.requires_grad for t in (weight, bias, g0, g1, b0, b1))
+        # (grad mode is off inside Function.forward; needs_input_grad already reflects no_grad callers)
+        need_grad = training and any(ctx.needs_input_grad[1:7])
         token = _Token() if need_grad else None
         ws = plan.workspace(training, x.device, token)
         gamma = torch.cat([g0, g1]) if g1.numel() else g0

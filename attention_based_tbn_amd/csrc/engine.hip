@@ -391,6 +391,37 @@ int tbn_backbone_conv_info(const tbn_backbone_plan* P, int idx, tbn_conv_info* i
   return TBN_ERR_ARG;
 }
 
+// debugging / per-layer parity tests: where one conv's tensors live inside the workspace.
+// kind 0: z = relu(bn(conv)) destination slice; 1: raw conv output y (after backward: dy);
+// 2: gradient wrt z.  offset in floats (for kind 2 of the final block the gradient is external: -1).
+int tbn_backbone_tensor_info(const tbn_backbone_plan* P, const char* conv_name, int kind, long* offset, int* rows,
+                             int* cols, int* ld) {
+  for (auto& c : P->convs) {
+    int col = 0;
+    for (int i = 0; i < c.nparts; ++i) {
+      if (c.names[i] == conv_name) {
+        const Buf& db = P->bufs[c.dst_buf[i]];
+        *rows = P->frames * c.outH * c.outW;
+        *cols = c.couts[i];
+        if (kind == 1) {
+          *offset = (long)(c.y_off + col);
+          *ld = c.cout;
+        } else if (kind == 0) {
+          *offset = (long)(db.off + c.dst_choff[i]);
+          *ld = db.C;
+        } else {
+          *offset = c.dst_buf[i] == P->out_buf ? -1 : (long)(db.doff + c.dst_choff[i]);
+          *ld = db.C;
+        }
+        return TBN_OK;
+      }
+      col += c.couts[i];
+    }
+  }
+  tbn_set_error("tensor_info: unknown conv '%s'", conv_name);
+  return TBN_ERR_ARG;
+}
+
 size_t tbn_backbone_weight_floats(const tbn_backbone_plan* P) { return P->weight_floats; }
 size_t tbn_backbone_channel_floats(const tbn_backbone_plan* P) { return P->chan_floats; }
 size_t tbn_backbone_workspace_bytes(const tbn_backbone_plan* P, int training) {

@@ -45,6 +45,15 @@ CONV_CASES = [
     (1, 15, 15, 64, 64, 3, 2, 1),
     (5, 7, 7, 192, 352, 1, 1, 0),
     (2, 8, 8, 1056, 384, 1, 1, 0),
+    # audio-shaped (non-square, tiny) maps of the 64x256 test spectrogram
+    (3, 2, 8, 192, 320, 3, 1, 1),
+    (3, 2, 8, 1056, 704, 1, 1, 0),
+    (3, 4, 16, 608, 448, 1, 1, 0),
+    (3, 4, 16, 192, 256, 3, 2, 1),
+    (3, 4, 16, 160, 192, 3, 1, 1),
+    (3, 2, 8, 1024, 128, 1, 1, 0),
+    (3, 2, 8, 1024, 736, 1, 1, 0),
+    (3, 4, 16, 192, 192, 3, 1, 1),
 ]
 
 
@@ -123,7 +132,8 @@ def test_wgrad_splitk_large_m():
     assert relerr(dw.permute(0, 3, 1, 2), wr.grad) < TOL
 
 
-@pytest.mark.parametrize("p_c", [(2 * 14 * 14, 96), (3 * 7 * 5, 384), (1000, 32)])
+@pytest.mark.parametrize("p_c", [(2 * 14 * 14, 96), (3 * 7 * 5, 384), (1000, 32), (48, 704), (48, 128), (192, 192),
+                                 (5000, 736)])
 def test_bn_relu_train_fwd_bwd(p_c):
     P, C = p_c
     y = torch.randn(P, C, generator=g(1)) * 2 + 0.5
