@@ -39,9 +39,115 @@ static void conv_geom(ConvP* p, int n, int h, int w, int cin, int cout, int k, i
   p->K = k * k * cin;
 }
 
+// ------------------------------------------------------------------ in-process conv-GEMM profiler
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+namespace {
+struct ProfRec {
+  int name;
+  double flops;
+  hipEvent_t a, b;
+};
+struct ProfAgg {
+  long launches = 0;
+  double ms = 0, flops = 0;
+};
+std::mutex g_prof_mu;
+bool g_prof_on = false;
+std::vector<std::string> g_prof_names;
+std::vector<ProfRec> g_prof_recs;
+std::vector<hipEvent_t> g_prof_pool;
+std::map<std::string, ProfAgg> g_prof_agg;
+std::vector<std::string> g_prof_keys;
+int g_prof_open = -1;
+
+hipEvent_t prof_event() {
+  if (!g_prof_pool.empty()) {
+    hipEvent_t e = g_prof_pool.back();
+    g_prof_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e;
+  hipEventCreate(&e);
+  return e;
+}
+void prof_collect() {
+  for (auto& r : g_prof_recs) {
+    hipEventSynchronize(r.b);
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, r.a, r.b);
+    ProfAgg& a = g_prof_agg[g_prof_names[r.name]];
+    a.launches += 1;
+    a.ms += ms;
+    a.flops += r.flops;
+    g_prof_pool.push_back(r.a);
+    g_prof_pool.push_back(r.b);
+  }
+  g_prof_recs.clear();
+  g_prof_keys.clear();
+  for (auto& kv : g_prof_agg) g_prof_keys.push_back(kv.first);
+}
+}  // namespace
+
+void tbn_prof_begin(const char* kernel, double flops, hipStream_t st) {
+  if (!g_prof_on) return;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  int idx = -1;
+  for (size_t i = 0; i < g_prof_names.size(); ++i)
+    if (g_prof_names[i] == kernel) idx = (int)i;
+  if (idx < 0) {
+    g_prof_names.push_back(kernel);
+    idx = (int)g_prof_names.size() - 1;
+  }
+  ProfRec r;
+  r.name = idx;
+  r.flops = flops;
+  r.a = prof_event();
+  r.b = prof_event();
+  hipEventRecord(r.a, st);
+  g_prof_recs.push_back(r);
+  g_prof_open = (int)g_prof_recs.size() - 1;
+}
+void tbn_prof_end(hipStream_t st) {
+  if (!g_prof_on) return;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  if (g_prof_open >= 0) hipEventRecord(g_prof_recs[g_prof_open].b, st);
+  g_prof_open = -1;
+}
+
 extern "C" {
 
 int tbn_version(void) { return 100; }
+
+int tbn_profile_enable(int on) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  g_prof_on = on != 0;
+  return TBN_OK;
+}
+int tbn_profile_reset(void) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  prof_collect();
+  g_prof_agg.clear();
+  g_prof_keys.clear();
+  return TBN_OK;
+}
+int tbn_profile_num_entries(void) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  prof_collect();
+  return (int)g_prof_keys.size();
+}
+int tbn_profile_entry(int i, char* name, int name_len, long* launches, double* total_ms, double* total_flops) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  TBN_REQUIRE(i >= 0 && i < (int)g_prof_keys.size() && name && name_len > 0, "profile_entry: bad index");
+  const ProfAgg& a = g_prof_agg[g_prof_keys[i]];
+  snprintf(name, name_len, "%s", g_prof_keys[i].c_str());
+  if (launches) *launches = a.launches;
+  if (total_ms) *total_ms = a.ms;
+  if (total_flops) *total_flops = a.flops;
+  return TBN_OK;
+}
 const char* tbn_last_error(void) { return g_err; }
 
 int tbn_conv2d_stat_tiles(int n, int h, int w, int cin, int cout, int ksize, int stride, int pad) {

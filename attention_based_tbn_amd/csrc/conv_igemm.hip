@@ -20,6 +20,8 @@
 //   weights (`up` = forward stride handles strided layers by zero-insertion on the fly).
 // ROWMODE is the 7x7 stem: input is NHWC padded to `cp` channels, a filter row (7*cp floats,
 //   padded to a multiple of 32) is one contiguous K run.
+#include <cstdio>
+
 #include "tbn_common.h"
 #include "tbn_kernels.h"
 
@@ -453,6 +455,12 @@ int tbn_launch_conv(ConvP p, int rowmode, int mt, int nt, hipStream_t st) {
   if (mt <= 0 || nt <= 0) tbn_conv_pick_tile(p.M, p.Cout, p.K, &mt, &nt);
   p.tiles_m = cdiv(p.M, 128 * mt);
   p.tiles_n = cdiv(p.Cout, 32 * nt);
+  if (p.alg_flops <= 0.0) p.alg_flops = 2.0 * p.M * (double)p.Cout * p.K;
+  {
+    char nm[64];
+    snprintf(nm, sizeof(nm), "conv_igemm_kernel<%d, %d, %s>", mt, nt, rowmode ? "true" : "false");
+    tbn_prof_begin(nm, p.alg_flops, st);
+  }
 #define TBN_CASE(MTv, NTv)                                     \
   if (mt == MTv && nt == NTv) {                                \
     if (rowmode)                                               \
@@ -466,6 +474,7 @@ int tbn_launch_conv(ConvP p, int rowmode, int mt, int nt, hipStream_t st) {
     return TBN_ERR_UNSUPPORTED;
   }
 #undef TBN_CASE
+  tbn_prof_end(st);
   TBN_CHECK_LAUNCH("conv_igemm");
   return TBN_OK;
 }
@@ -514,6 +523,12 @@ int tbn_launch_wgrad(WgradP p, int rowmode, float* dw, float* workspace, hipStre
   TBN_REQUIRE(splits == 1 || workspace != nullptr, "wgrad: split-K needs a workspace");
   p.out = splits > 1 ? workspace : dw;
   const int blocks = p.tiles_co * p.tiles_ci * p.taps * splits;
+  if (p.alg_flops <= 0.0) p.alg_flops = 2.0 * p.M * (double)p.Cout * p.K;
+  {
+    char nm[64];
+    snprintf(nm, sizeof(nm), "conv_wgrad_kernel<%d, %d, %s>", mt, nt, rowmode ? "true" : "false");
+    tbn_prof_begin(nm, p.alg_flops, st);
+  }
 #define TBN_CASE(MTv, NTv)                                          \
   if (mt == MTv && nt == NTv) {                                     \
     if (rowmode)                                                    \
@@ -526,6 +541,7 @@ int tbn_launch_wgrad(WgradP p, int rowmode, float* dw, float* workspace, hipStre
     return TBN_ERR_UNSUPPORTED;
   }
 #undef TBN_CASE
+  tbn_prof_end(st);
   TBN_CHECK_LAUNCH("conv_wgrad");
   if (splits > 1) {
     const size_t n = (size_t)p.Cout * p.K;

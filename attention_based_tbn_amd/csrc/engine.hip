@@ -481,6 +481,7 @@ int tbn_backbone_forward(const tbn_backbone_plan* P, int training, const float* 
       p.up = 1;
       p.M = R * c.outH * c.outW;
       p.bias = prm->bias + c.c_off;
+      p.alg_flops = 2.0 * p.M * (double)c.cout * c.k * c.k * c.cin;
       if (c.stem) {
         p.wt = wpack;
         p.Cin = P->kw;
@@ -614,6 +615,7 @@ int tbn_backbone_backward(const tbn_backbone_plan* P, const float* dfeatures, co
       wp.stride = c.stride;
       wp.pad = c.pad;
       wp.M = M;
+      wp.alg_flops = 2.0 * M * (double)c.cout * c.k * c.k * c.cin;
       if (c.stem) {
         wp.Cin = P->kw;
         wp.R = 7;
@@ -652,6 +654,7 @@ int tbn_backbone_backward(const tbn_backbone_plan* P, const float* dfeatures, co
       p.up = c.stride;
       p.M = R * c.inH * c.inW;
       p.K = c.k * c.k * c.cout;
+      p.alg_flops = 2.0 * M * (double)c.cout * c.k * c.k * c.cin;  // = forward count (zero-insertion not counted)
       p.mode = CONV_EPI_PLAIN;
       p.flags = c.dgrad_accum ? CONV_FLAG_ACCUM : 0;
       p.nseg = 1;

@@ -24,6 +24,7 @@ struct ConvP {
   int cp;                 // ROWMODE: channels per pixel of the padded NHWC input
   int tiles_m, tiles_n;
   int mode, flags;
+  double alg_flops;       // host only: algorithmic FLOPs of this launch (profiling)
 };
 
 struct WgradP {
@@ -40,7 +41,12 @@ struct WgradP {
   int tiles_co, tiles_ci;
   int rows_per_split;
   FastDiv div_ohw, div_ow;
+  double alg_flops;       // host only
 };
+
+// optional in-process profiler: brackets every conv-GEMM launch with hipEvents on its stream
+void tbn_prof_begin(const char* kernel, double flops, hipStream_t st);
+void tbn_prof_end(hipStream_t st);
 
 // conv_igemm.hip
 void tbn_conv_pick_tile(int M, int Cout, int K, int* mt, int* nt);

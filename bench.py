@@ -1,0 +1,202 @@
+#!/usr/bin/env python
+"""Headline benchmark: clips/s of the 3-segment RGB+Flow+Audio TBN training step (fwd+bwd)
+on N MI355X GPUs of one node (BASELINE.json config 4: async sampling, attention off, 1.279 s
+audio, batch 32 clips per GPU -- global batch 256 at 8 GPUs, i.e. weak scaling).
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = forward + loss + backward (+ RCCL gradient all-reduce for N>1) + clip_grad_norm(20) +
+SGD(momentum) update, exactly the reference loop body (core/tools/train.py:69-94), on synthetic
+inputs already resident in HBM.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOP_PER_CLIP_FWD_BWD = 120.63e9      # BASELINE.md section 3 (convs only, 3 modalities x 3 segments)
+PEAK_FP32_MFMA_TFLOPS = 157.3         # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+
+
+def synthetic_batch(B, n, device, seed):
+    g = torch.Generator(device=device).manual_seed(seed)
+    mean = torch.tensor([0.408, 0.459, 0.502], device=device).view(1, 1, 3, 1, 1)
+    inp = {
+        "RGB": torch.rand(B, n, 3, 224, 224, device=device, generator=g) - mean,
+        "Flow": torch.rand(B, n, 10, 224, 224, device=device, generator=g) - 0.502,
+        "Audio": (torch.randn(B, n, 1, 256, 256, device=device, generator=g) * 3 - 6).clamp_(-13.8155, 8.0),
+    }
+    tgt = {"class": {"verb": torch.randint(0, 125, (B,), device=device, generator=g),
+                     "noun": torch.randint(0, 352, (B,), device=device, generator=g)}}
+    return inp, tgt
+
+
+def collect_profile():
+    from attention_based_tbn_amd._lib import lib
+    L = lib()
+    out = []
+    name = C.create_string_buffer(96)
+    for i in range(L.tbn_profile_num_entries()):
+        n, ms, fl = C.c_long(), C.c_double(), C.c_double()
+        L.tbn_profile_entry(i, name, 96, C.byref(n), C.byref(ms), C.byref(fl))
+        out.append({"kernel": name.value.decode(), "launches": n.value, "ms": ms.value, "flops": fl.value})
+    return out
+
+
+def cpu_baseline(seconds_budget=25.0):
+    """the CPU oracle (torch-CPU restatement of the reference path) on this box's host cores:
+    same config-4 graph and full-size inputs, B=2 clips x 3 segments, fwd+loss+bwd"""
+    from attention_based_tbn_amd.config import load_config, get_modality
+    from oracle.fill import pretrained_pair
+    from oracle.tbn import build_model as build_oracle
+    cfg = load_config(["model.attention.enable=False", "data.audio.audio_length=1.279", "data.sampling=async"])
+    modality = get_modality(cfg)
+    torch.manual_seed(0)
+    model, crit, _ = build_oracle(cfg, modality, pretrained_pair(7))
+    model.train()
+    B, n = 2, 3
+    g = torch.Generator().manual_seed(0)
+    inp = {"RGB": torch.rand(B, n, 3, 224, 224, generator=g) - 0.45,
+           "Flow": torch.rand(B, n, 10, 224, 224, generator=g) - 0.5,
+           "Audio": torch.randn(B, n, 1, 256, 256, generator=g) * 3 - 6}
+    tgt = {"class": {"verb": torch.randint(0, 125, (B,), generator=g), "noun": torch.randint(0, 352, (B,), generator=g)}}
+
+    def step():
+        model.zero_grad()
+        out = model(inp)
+        loss, _ = model.get_loss(crit, tgt, out, 0)
+        loss["total"].backward()
+
+    step()  # warm-up
+    t0 = time.perf_counter()
+    steps = 0
+    while steps < 2 or (time.perf_counter() - t0 < seconds_budget and steps < 8):
+        step()
+        steps += 1
+    dt = time.perf_counter() - t0
+    return {"value": B * steps / dt, "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{steps} fwd+bwd steps of the config-4 graph at B={B} clips x {n} segments, full-size "
+                      f"synthetic inputs, oracle/ (torch-CPU fp32, oneDNN) on the GPU box's host cores"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch-per-gpu", type=int, default=32)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-every", type=int, default=5, help="bracket conv-GEMM launches with HIP events on every k-th timed step")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+
+    from attention_based_tbn_amd.config import load_config, get_modality
+    from attention_based_tbn_amd.core.models import build_model
+    from attention_based_tbn_amd._lib import lib
+    cfg = load_config(["model.attention.enable=False", "data.audio.audio_length=1.279", "data.sampling=async"])
+    modality = get_modality(cfg)
+    torch.manual_seed(0)
+    model, criterion, _ = build_model(cfg, modality, device)
+    model.train()
+    params = [p for p in model.parameters() if p.requires_grad]
+    opt = torch.optim.SGD(params, lr=cfg.train.optim.lr, momentum=cfg.train.optim.momentum,
+                          weight_decay=cfg.train.optim.weight_decay)
+    B, n = args.batch_per_gpu, cfg.train.num_segments
+    inp, tgt = synthetic_batch(B, n, device, seed=rank)   # clips are sharded by rank: no data-path collective
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        out = model(inp)
+        loss, _ = model.get_loss(criterion, tgt, out, 0)
+        loss["total"].backward()              # N>1: gradient all-reduce is issued inside backward, waited at its end
+        torch.nn.utils.clip_grad_norm_(params, cfg.train.clip_grad)
+        opt.step()
+        return loss["total"]
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    L = lib()
+    L.tbn_profile_reset()
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        prof = args.profile_every > 0 and (i % args.profile_every == 0)
+        if prof:
+            L.tbn_profile_enable(1)
+        loss = step()
+        if prof:
+            L.tbn_profile_enable(0)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert torch.isfinite(loss).item(), "loss is not finite"
+
+    if rank == 0:
+        clips = B * world * args.steps
+        value = clips / dt
+        prof = sorted(collect_profile(), key=lambda e: -e["ms"])
+        roofline = None
+        if prof:
+            top = prof[0]
+            ach = top["flops"] / (top["ms"] * 1e-3) / 1e12
+            tot_ms, tot_fl = sum(e["ms"] for e in prof), sum(e["flops"] for e in prof)
+            roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                        "kernel": top["kernel"], "launches": top["launches"],
+                        "avg_launch_us": round(1e3 * top["ms"] / top["launches"], 2),
+                        "alg_gflop_per_launch": round(top["flops"] / top["launches"] / 1e9, 4),
+                        "all_conv_gemm": {"achieved": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2),
+                                          "frac": round(tot_fl / (tot_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                                          "ms_per_profiled_step": round(tot_ms / max(1, len(range(0, args.steps, args.profile_every))), 2)},
+                        "end_to_end_frac": round(value / world * FLOP_PER_CLIP_FWD_BWD / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                        "by_kernel": [{"kernel": e["kernel"], "launches": e["launches"],
+                                       "avg_us": round(1e3 * e["ms"] / e["launches"], 2),
+                                       "tflops": round(e["flops"] / (e["ms"] * 1e-3) / 1e12, 2)} for e in prof[:8]]}
+        line = {
+            "metric": "clips/sec (3-seg RGB+Flow+Audio TBN fwd+bwd)", "value": round(value, 2), "unit": "clips/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE config 4: RGB+Flow+Audio async, attention off, 3 segments, 224x224 frames "
+                                   "+ 1.279 s (256x256) spectrogram, train step fwd+loss+bwd+clip+SGD",
+                       "batch_per_gpu": B, "global_batch": B * world, "segments": n,
+                       "parallelism": f"dp{world}" if world > 1 else "single"},
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -30,6 +30,16 @@ extern "C" {
 int tbn_version(void);
 const char* tbn_last_error(void);
 
+/* measurement aid (bench.py roofline): while enabled, every conv-GEMM launch (forward / data-grad /
+ * weight-grad implicit GEMMs) is bracketed by hipEvents recorded on the launch stream; entries
+ * aggregate, per kernel instantiation, the launch count, summed event time and summed algorithmic
+ * FLOPs (2*M*Cout*R*S*Cin of the convolution; padding / zero-insertion work is not counted).
+ * tbn_profile_num_entries() synchronises the recorded events. */
+int tbn_profile_enable(int on);
+int tbn_profile_reset(void);
+int tbn_profile_num_entries(void);
+int tbn_profile_entry(int i, char* name, int name_len, long* launches, double* total_ms, double* total_flops);
+
 /* ---- BN-Inception backbone engine -------------------------------------------------------------
  * replaces: BNInception.features() as instantiated by reference core/models/bn_inception.py:38-107
  * (graph core/models/bn_inception_audio.py:58-404,437-1003 with the 7x7 stem), called from
