@@ -56,6 +56,8 @@ struct ProfAgg {
 };
 std::mutex g_prof_mu;
 bool g_prof_on = false;
+bool g_prof_layers = false;   // enable(2): key = "kernel | layer label"
+std::string g_prof_label;
 std::vector<std::string> g_prof_names;
 std::vector<ProfRec> g_prof_recs;
 std::vector<hipEvent_t> g_prof_pool;
@@ -94,6 +96,9 @@ void prof_collect() {
 void tbn_prof_begin(const char* kernel, double flops, hipStream_t st) {
   if (!g_prof_on) return;
   std::lock_guard<std::mutex> lk(g_prof_mu);
+  std::string key = kernel;
+  if (g_prof_layers) key += " | " + g_prof_label;
+  kernel = key.c_str();
   int idx = -1;
   for (size_t i = 0; i < g_prof_names.size(); ++i)
     if (g_prof_names[i] == kernel) idx = (int)i;
@@ -110,6 +115,11 @@ void tbn_prof_begin(const char* kernel, double flops, hipStream_t st) {
   g_prof_recs.push_back(r);
   g_prof_open = (int)g_prof_recs.size() - 1;
 }
+void tbn_prof_label(const char* label) {
+  if (!g_prof_on || !g_prof_layers) return;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  g_prof_label = label;
+}
 void tbn_prof_end(hipStream_t st) {
   if (!g_prof_on) return;
   std::lock_guard<std::mutex> lk(g_prof_mu);
@@ -124,6 +134,7 @@ int tbn_version(void) { return 100; }
 int tbn_profile_enable(int on) {
   std::lock_guard<std::mutex> lk(g_prof_mu);
   g_prof_on = on != 0;
+  g_prof_layers = on == 2;
   return TBN_OK;
 }
 int tbn_profile_reset(void) {

@@ -27,7 +27,41 @@
 
 #define LDT 36  // LDS row pitch in floats (32 + 4): 16-B aligned rows, conflict-free b128 reads
 
-template <int MT, int NT, bool ROWMODE>
+// Hardware-bounds-checked 16-B loads.  ROCm 7.2's clang lowers __builtin_amdgcn_raw_buffer_load_b128 to a
+// ONE-dword load, so the LLVM intrinsic is bound directly (same idiom as composable_kernel).
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+__device__ f32x4 tbn_llvm_buffer_load_f32x4(i32x4 srsrc, int voffset, int soffset, int aux) __asm(
+    "llvm.amdgcn.raw.buffer.load.v4f32");
+#define TBN_OOB 0x80000000u  // byte offset beyond any buffer extent (< 2 GiB enforced) -> hardware returns 0
+
+// 128-bit buffer descriptor from wave-uniform kernel arguments (base, extent in bytes)
+__device__ __forceinline__ i32x4 make_rsrc(const void* ptr, unsigned bytes) {
+  union {
+    i32x4 v;
+    struct {
+      const void* p;
+      unsigned range, cfg;
+    } s;
+  } u;
+  u.s.p = ptr;
+  u.s.range = bytes;
+  u.s.cfg = 0x00020000u;
+  i32x4 r;
+  r.x = __builtin_amdgcn_readfirstlane(u.v.x);
+  r.y = __builtin_amdgcn_readfirstlane(u.v.y);
+  r.z = __builtin_amdgcn_readfirstlane(u.v.z);
+  r.w = __builtin_amdgcn_readfirstlane(u.v.w);
+  return r;
+}
+
+__device__ __forceinline__ float4 buf_load4(i32x4 r, unsigned voff) {
+  const f32x4 v = tbn_llvm_buffer_load_f32x4(r, (int)voff, 0, 0);
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+
+// EPI: 0 plain (+bias, optional ReLU / accumulate), 1 training-BN statistics, 2 eval-BN fold + ReLU,
+//      3 plain with output scatter (parity phase of a strided data gradient)
+template <int MT, int NT, bool ROWMODE, int EPI>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
   constexpr int BM = 128 * MT, BN = 32 * NT;
   constexpr int AR = 4 * MT;  // A rows per thread
@@ -44,23 +78,42 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
   const int tm = nid / p.tiles_n, tn = nid - tm * p.tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
 
+  // descriptors are built from kernel arguments only (wave-uniform): loads need no branches, an
+  // out-of-image tap / out-of-range row is an out-of-range OFFSET and reads zeros
+  const i32x4 in_rsrc = make_rsrc(p.in, p.in_bytes);
+  const i32x4 wt_rsrc = make_rsrc(p.wt, p.wt_bytes);
+
   const int c4 = tid & 7, r0 = tid >> 3;
-  int a_base[AR];  // pixel index of (n,0,0), or -1 when the output row is out of range
-  int a_yx[AR];    // packed (iy0 << 16) | (ix0 & 0xffff)
+  unsigned a_off[AR];   // byte offset of the row's (n, iy0, ix0) pixel (wraps for negative ix0 in ROWMODE)
+  unsigned a_mask[AR];  // bit t: tap t of this row lies inside the image (ROWMODE: bit r = filter row)
+  int a_ix[AR];         // ROWMODE: first input column of the row's window
   {
-    const int ohw = p.OH * p.OW;
+    const int ohw = p.OHs * p.OWs;
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
       const int m = m0 + r0 + 32 * i;
+      unsigned mask = 0;
+      int off = 0, ix0 = 0;
       if (m < p.M) {
         const int n = m / ohw, rem = m - n * ohw;
-        const int oy = rem / p.OW, ox = rem - oy * p.OW;
-        a_base[i] = n * p.H * p.W;
-        a_yx[i] = ((oy * p.stride - p.pad) << 16) | ((ox * p.stride - p.pad) & 0xffff);
-      } else {
-        a_base[i] = -1;
-        a_yx[i] = 0;
+        const int a = rem / p.OWs, b = rem - a * p.OWs;
+        const int iy0 = a * p.in_sy;
+        ix0 = b * p.in_sx;
+        if (ROWMODE) {
+          ix0 -= p.pad;
+          off = ((n * p.H + iy0) * p.W + ix0) * p.cp * 4;
+          for (int t = 0; t < p.ntaps; ++t)
+            if ((unsigned)(iy0 + p.tap_dy[t]) < (unsigned)p.H) mask |= 1u << t;
+        } else {
+          off = ((n * p.H + iy0) * p.W + ix0) * p.in_ld * 4;
+          for (int t = 0; t < p.ntaps; ++t)
+            if ((unsigned)(iy0 + p.tap_dy[t]) < (unsigned)p.H && (unsigned)(ix0 + p.tap_dx[t]) < (unsigned)p.W)
+              mask |= 1u << t;
+        }
       }
+      a_off[i] = (unsigned)off;
+      a_mask[i] = mask;
+      a_ix[i] = ix0;
     }
   }
 
@@ -75,50 +128,30 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
   const int cps = p.Cin >> 5;  // 32-float chunks per tap
   const int ksteps = p.K >> 5;
   float4 ra[AR], rb[NT];
+  const unsigned b_row = (unsigned)(n0 + r0) * (unsigned)p.Krow * 4u + (unsigned)c4 * 16u;
 
   auto load_tiles = [&](int ks) {
     const int tap = ks / cps;
     const int c0 = (ks - tap * cps) << 5;
-    int r, s;
-    if (ROWMODE) {
-      r = tap;
-      s = 0;
-    } else {
-      r = tap / p.S;
-      s = tap - r * p.S;
-    }
     const int cc = c0 + c4 * 4;
+    if (!ROWMODE) {
+      const unsigned toff = (unsigned)((p.tap_dy[tap] * p.W + p.tap_dx[tap]) * p.in_ld * 4 + cc * 4);
 #pragma unroll
-    for (int i = 0; i < AR; ++i) {
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (a_base[i] >= 0) {
-        int iy = (a_yx[i] >> 16) + r;
-        int ix = (int)(short)(a_yx[i] & 0xffff) + s;
-        bool ok = true;
-        if (p.up > 1) {  // data-gradient of a strided conv: only every `up`-th position exists
-          ok = (iy >= 0) && (ix >= 0) && ((iy % p.up) == 0) && ((ix % p.up) == 0);
-          iy /= p.up;
-          ix /= p.up;
-        }
-        if (!ROWMODE) {
-          ok = ok && ((unsigned)iy < (unsigned)p.H) && ((unsigned)ix < (unsigned)p.W);
-          if (ok) v = *reinterpret_cast<const float4*>(p.in + (size_t)(a_base[i] + iy * p.W + ix) * p.in_ld + cc);
-        } else {
-          const int px = ix + cc / p.cp;
-          ok = ((unsigned)iy < (unsigned)p.H) && ((unsigned)px < (unsigned)p.W);
-          if (ok)
-            v = *reinterpret_cast<const float4*>(p.in + (ptrdiff_t)(a_base[i] + iy * p.W) * p.cp +
-                                                 ((ptrdiff_t)ix * p.cp + cc));
-        }
+      for (int i = 0; i < AR; ++i)
+        ra[i] = buf_load4(in_rsrc, ((a_mask[i] >> tap) & 1u) ? a_off[i] + toff : TBN_OOB);
+    } else {
+      const unsigned toff = (unsigned)(p.tap_dy[tap] * p.W * p.cp * 4 + cc * 4);
+      const int dpx = cc / p.cp;
+#pragma unroll
+      for (int i = 0; i < AR; ++i) {
+        const bool ok = ((a_mask[i] >> tap) & 1u) && ((unsigned)(a_ix[i] + dpx) < (unsigned)p.W);
+        ra[i] = buf_load4(in_rsrc, ok ? a_off[i] + toff : TBN_OOB);
       }
-      ra[i] = v;
     }
+    const unsigned koff = (unsigned)(p.tap_koff[tap] + c0) * 4u;
 #pragma unroll
-    for (int i = 0; i < NT; ++i) {
-      const int co = n0 + r0 + 32 * i;
-      rb[i] = (co < p.Cout) ? *reinterpret_cast<const float4*>(p.wt + (size_t)co * p.K + (ks << 5) + c4 * 4)
-                            : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+    for (int i = 0; i < NT; ++i)  // rows >= Cout are beyond wt_bytes -> zeros
+      rb[i] = buf_load4(wt_rsrc, b_row + (unsigned)(32 * i) * (unsigned)p.Krow * 4u + koff);
   };
   auto store_tiles = [&]() {
 #pragma unroll
@@ -132,6 +165,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
   __syncthreads();
 
   const int lrow = lane & 31, lhalf = lane >> 5;
+  int nt_act = (p.Cout - n0 + 31) >> 5;  // active 32-column sub-tiles of this block (block-uniform)
+  if (nt_act > NT) nt_act = NT;
   for (int ks = 0; ks < ksteps; ++ks) {
     const bool more = (ks + 1 < ksteps);
     if (more) load_tiles(ks + 1);  // global loads stay in flight under the MFMA phase
@@ -145,16 +180,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
       for (int j = 0; j < NT; ++j)
         b[j] = *reinterpret_cast<const float4*>(&Bs[(j * 32 + lrow) * LDT + kg * 8 + lhalf * 4]);
 #pragma unroll
-      for (int i = 0; i < MT; ++i)
+      for (int j = 0; j < NT; ++j) {
+        if (j < nt_act) {
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-          if (n0 + j * 32 < p.Cout) {
+          for (int i = 0; i < MT; ++i) {
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
           }
         }
+      }
     }
     __syncthreads();
     if (more) {
@@ -165,6 +201,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
 
   // ---------------------------------------------------------------- epilogue
   float* red = lds;  // [2][4 waves][BN] for the BN-statistics partials (tiles are dead now)
+  const int mrow0 = m0 + wave * 32 * MT + 4 * lhalf;  // + i*32 + 8*g + q  (accumulator register e = 4*g + q)
+  const bool tile_full = (m0 + BM <= p.M);
+  constexpr bool scatter = (EPI == 3);  // strided data-gradient phase
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     const int colb = n0 + j * 32;
@@ -178,22 +217,30 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
     const int old = p.seg[sg].ld;
     const float bias = (p.bias != nullptr && col_ok) ? p.bias[col] : 0.f;
     float sc = 1.f, sh = 0.f;
-    if (p.mode == CONV_EPI_EVAL && col_ok) {
+    if (EPI == 2 && col_ok) {
       sc = p.scale[col];
       sh = p.shift[col];
     }
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
+      float* rowp = obase + (size_t)(mrow0 + i * 32) * old;
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const int m = m0 + wave * 32 * MT + i * 32 + 8 * (e >> 2) + 4 * lhalf + (e & 3);
+        const int dm = 8 * (e >> 2) + (e & 3);
+        const int m = mrow0 + i * 32 + dm;
         float v = acc[i][j][e] + bias;
-        if (m < p.M && col_ok) {
-          float* o = obase + (size_t)m * old;
-          if (p.mode == CONV_EPI_EVAL) {
+        if ((tile_full || m < p.M) && col_ok) {
+          float* o = rowp + dm * old;
+          if (scatter) {
+            const int ohw = p.OHs * p.OWs;
+            const int n = m / ohw, rem = m - n * ohw;
+            const int a = rem / p.OWs, b = rem - a * p.OWs;
+            o = obase + (((size_t)n * p.OH + (a * p.out_sy + p.out_oy)) * p.OW + (b * p.out_sx + p.out_ox)) * old;
+          }
+          if (EPI == 2) {
             v = fmaxf(fmaf(v, sc, sh), 0.f);
-          } else if (p.mode == CONV_EPI_STATS) {
+          } else if (EPI == 1) {
             s1 += v;
             s2 = fmaf(v, v, s2);
           } else {
@@ -204,7 +251,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
         }
       }
     }
-    if (p.mode == CONV_EPI_STATS) {
+    if (EPI == 1) {
       s1 += __shfl_xor(s1, 32);
       s2 += __shfl_xor(s2, 32);
       if (lhalf == 0) {
@@ -213,7 +260,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
       }
     }
   }
-  if (p.mode == CONV_EPI_STATS) {
+  if (EPI == 1) {
     __syncthreads();
     if (tid < BN && n0 + tid < p.Cout) {
       float t1 = 0.f, t2 = 0.f;
@@ -279,42 +326,39 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
   constexpr int AI = (AF + 63) / 64, BI = (BF + 63) / 64;
   float4 ra[AI], rb[BI];
 
+  const i32x4 dy_rsrc = make_rsrc(p.dy, p.dy_bytes);
+  const i32x4 x_rsrc = make_rsrc(p.x, p.x_bytes);
   auto load_tiles = [&](int row0) {
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
       const int f = lane + 64 * i;
       const int row = f / (8 * MT), c = (f - row * (8 * MT)) * 4;
       const int m = row0 + row;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (f < AF && m < pend && co0 + c < p.Cout)
-        v = *reinterpret_cast<const float4*>(p.dy + (size_t)m * p.dy_ld + co0 + c);
-      ra[i] = v;
+      const bool ok = (f < AF) && (m < pend) && (co0 + c < p.Cout);
+      ra[i] = buf_load4(dy_rsrc, ok ? ((unsigned)m * (unsigned)p.dy_ld + (unsigned)(co0 + c)) * 4u : TBN_OOB);
     }
 #pragma unroll
     for (int i = 0; i < BI; ++i) {
       const int f = lane + 64 * i;
       const int row = f / (8 * NT), c = (f - row * (8 * NT)) * 4;
       const int m = row0 + row;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (f < BF && m < pend && ci0 + c < p.Cin) {
-        const uint32_t n = fdiv((uint32_t)m, p.div_ohw);
-        const uint32_t rem = (uint32_t)m - n * p.div_ohw.d;
-        const uint32_t oy = fdiv(rem, p.div_ow);
-        const uint32_t ox = rem - oy * p.div_ow.d;
-        const int iy = (int)oy * p.stride - p.pad + r;
-        const int ix = (int)ox * p.stride - p.pad + s;
-        const int cc = ci0 + c;
-        if (!ROWMODE) {
-          if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
-            v = *reinterpret_cast<const float4*>(p.x + (size_t)((n * p.H + iy) * p.W + ix) * p.x_ld + cc);
-        } else {
-          const int px = ix + cc / p.cp;
-          if ((unsigned)iy < (unsigned)p.H && (unsigned)px < (unsigned)p.W)
-            v = *reinterpret_cast<const float4*>(p.x + (ptrdiff_t)((n * p.H + iy) * p.W) * p.cp +
-                                                 ((ptrdiff_t)ix * p.cp + cc));
-        }
+      const uint32_t n = fdiv((uint32_t)m, p.div_ohw);
+      const uint32_t rem = (uint32_t)m - n * p.div_ohw.d;
+      const uint32_t oy = fdiv(rem, p.div_ow);
+      const uint32_t ox = rem - oy * p.div_ow.d;
+      const int iy = (int)oy * p.stride - p.pad + r;
+      const int ix = (int)ox * p.stride - p.pad + s;
+      const int cc = ci0 + c;
+      bool ok = (f < BF) && (m < pend) && (cc < p.Cin) && ((unsigned)iy < (unsigned)p.H);
+      unsigned off;
+      if (!ROWMODE) {
+        ok = ok && ((unsigned)ix < (unsigned)p.W);
+        off = (((n * p.H + iy) * p.W + ix) * (unsigned)p.x_ld + (unsigned)cc) * 4u;
+      } else {
+        ok = ok && ((unsigned)(ix + cc / p.cp) < (unsigned)p.W);
+        off = (unsigned)((int)(((n * p.H + iy) * p.W) * (unsigned)p.cp) + ix * p.cp + cc) * 4u;
       }
-      rb[i] = v;
+      rb[i] = buf_load4(x_rsrc, ok ? off : TBN_OOB);
     }
   };
   auto store_tiles = [&]() {
@@ -417,9 +461,21 @@ __global__ void weight_flip_transpose_kernel(const float* __restrict__ w, float*
 }
 
 // ------------------------------------------------------------------------------------------ host
+template <int MT, int NT, bool RM, int EPI>
+static void launch_conv_e(const ConvP& p, hipStream_t st) {
+  hipLaunchKernelGGL((conv_igemm_kernel<MT, NT, RM, EPI>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, st, p);
+}
 template <int MT, int NT, bool RM>
 static void launch_conv(const ConvP& p, hipStream_t st) {
-  hipLaunchKernelGGL((conv_igemm_kernel<MT, NT, RM>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, st, p);
+  const bool scatter = (p.out_sy != 1) || (p.out_sx != 1);
+  if (p.mode == CONV_EPI_STATS)
+    launch_conv_e<MT, NT, RM, 1>(p, st);
+  else if (p.mode == CONV_EPI_EVAL)
+    launch_conv_e<MT, NT, RM, 2>(p, st);
+  else if (!RM && scatter)
+    launch_conv_e<MT, NT, false, 3>(p, st);
+  else
+    launch_conv_e<MT, NT, RM, 0>(p, st);
 }
 
 void tbn_conv_pick_tile(int M, int Cout, int K, int* mt_out, int* nt_out) {
@@ -446,19 +502,14 @@ void tbn_conv_pick_tile(int M, int Cout, int K, int* mt_out, int* nt_out) {
   *nt_out = bn;
 }
 
-int tbn_launch_conv(ConvP p, int rowmode, int mt, int nt, hipStream_t st) {
-  TBN_REQUIRE(p.K % 32 == 0 && p.Cin % 32 == 0, "conv: K (%d) and per-tap Cin (%d) must be multiples of 32", p.K,
-              p.Cin);
-  TBN_REQUIRE(p.in_ld % 4 == 0 && p.nseg >= 1 && p.nseg <= 3, "conv: bad in_ld %d / nseg %d", p.in_ld, p.nseg);
-  TBN_REQUIRE(p.up == 1 || p.up == 2, "conv: up must be 1 or 2");
-  TBN_REQUIRE(p.M > 0 && (long)p.N * p.H * p.W < (1l << 31), "conv: pixel count out of range");
+static int launch_conv_tiles(ConvP& p, int rowmode, int mt, int nt, hipStream_t st) {
   if (mt <= 0 || nt <= 0) tbn_conv_pick_tile(p.M, p.Cout, p.K, &mt, &nt);
   p.tiles_m = cdiv(p.M, 128 * mt);
   p.tiles_n = cdiv(p.Cout, 32 * nt);
-  if (p.alg_flops <= 0.0) p.alg_flops = 2.0 * p.M * (double)p.Cout * p.K;
   {
     char nm[64];
-    snprintf(nm, sizeof(nm), "conv_igemm_kernel<%d, %d, %s>", mt, nt, rowmode ? "true" : "false");
+    const int epi = p.mode == CONV_EPI_STATS ? 1 : (p.mode == CONV_EPI_EVAL ? 2 : ((p.out_sy != 1 || p.out_sx != 1) ? 3 : 0));
+    snprintf(nm, sizeof(nm), "conv_igemm_kernel<%d, %d, %s, %d>", mt, nt, rowmode ? "true" : "false", epi);
     tbn_prof_begin(nm, p.alg_flops, st);
   }
 #define TBN_CASE(MTv, NTv)                                     \
@@ -476,6 +527,78 @@ int tbn_launch_conv(ConvP p, int rowmode, int mt, int nt, hipStream_t st) {
 #undef TBN_CASE
   tbn_prof_end(st);
   TBN_CHECK_LAUNCH("conv_igemm");
+  return TBN_OK;
+}
+
+// Fills the derived geometry and launches.  `up == 2` (data gradient of a stride-2 conv; the caller
+// passes stride 1, pad = k-1-pad_fwd and tap-flipped weights) is decomposed into the 4 output-parity
+// phases: each phase only visits the taps that hit a real (non zero-inserted) dy sample, so no MFMA
+// work is spent on inserted zeros (2.25 instead of 9 taps per output pixel for 3x3).
+int tbn_launch_conv(ConvP p, int rowmode, int mt, int nt, hipStream_t st) {
+  TBN_REQUIRE(p.K % 32 == 0 && p.Cin % 32 == 0, "conv: K (%d) and per-tap Cin (%d) must be multiples of 32", p.K,
+              p.Cin);
+  TBN_REQUIRE(p.in_ld % 4 == 0 && p.nseg >= 1 && p.nseg <= 3, "conv: bad in_ld %d / nseg %d", p.in_ld, p.nseg);
+  TBN_REQUIRE(p.up == 1 || p.up == 2, "conv: up must be 1 or 2");
+  TBN_REQUIRE(p.M > 0, "conv: empty problem");
+  const size_t in_bytes = (size_t)p.N * p.H * p.W * (rowmode ? p.cp : p.in_ld) * sizeof(float);
+  TBN_REQUIRE(in_bytes < (1ull << 31), "conv: input extent %zu B >= 2 GiB (process the frames in chunks)", in_bytes);
+  p.in_bytes = (unsigned)in_bytes;
+  if (p.alg_flops <= 0.0) p.alg_flops = 2.0 * p.M * (double)p.Cout * p.K;
+  const int taps_full = rowmode ? p.R : p.R * p.S;
+  p.Krow = taps_full * p.Cin;
+  p.wt_bytes = (unsigned)((size_t)p.Cout * p.Krow * sizeof(float));
+  if (p.up == 1) {
+    TBN_REQUIRE(taps_full <= 9, "conv: at most 9 taps (3x3) on the generic path, 7 filter rows on the stem path");
+    p.OHs = p.OH;
+    p.OWs = p.OW;
+    p.out_sy = p.out_sx = 1;
+    p.out_oy = p.out_ox = 0;
+    p.in_sy = p.in_sx = p.stride;
+    p.ntaps = taps_full;
+    for (int t = 0; t < taps_full; ++t) {
+      const int r = rowmode ? t : t / p.S, s = rowmode ? 0 : t % p.S;
+      p.tap_dy[t] = (short)(r - p.pad);
+      p.tap_dx[t] = (short)(s - p.pad);
+      p.tap_koff[t] = t * p.Cin;
+    }
+    p.K = p.ntaps * p.Cin;
+    return launch_conv_tiles(p, rowmode, mt, nt, st);
+  }
+  TBN_REQUIRE(!rowmode && p.stride == 1 && p.R == p.S && p.R * p.S <= 9, "conv: unsupported strided data gradient");
+  const double flops_total = p.alg_flops;
+  const int full_M = p.N * p.OH * p.OW;
+  for (int py = 0; py < 2; ++py)
+    for (int px = 0; px < 2; ++px) {
+      ConvP q = p;
+      q.OHs = (p.OH - py + 1) / 2;
+      q.OWs = (p.OW - px + 1) / 2;
+      if (q.OHs <= 0 || q.OWs <= 0) continue;
+      q.out_sy = q.out_sx = 2;
+      q.out_oy = py;
+      q.out_ox = px;
+      q.in_sy = q.in_sx = 1;
+      q.ntaps = 0;
+      for (int r = 0; r < p.R; ++r) {
+        if (((py - p.pad + r) & 1) != 0) continue;
+        for (int s2 = 0; s2 < p.S; ++s2) {
+          if (((px - p.pad + s2) & 1) != 0) continue;
+          // floor division by 2 of a possibly negative even number
+          q.tap_dy[q.ntaps] = (short)((py - p.pad + r) / 2);
+          q.tap_dx[q.ntaps] = (short)((px - p.pad + s2) / 2);
+          q.tap_koff[q.ntaps] = (r * p.S + s2) * p.Cin;
+          ++q.ntaps;
+        }
+      }
+      q.M = p.N * q.OHs * q.OWs;
+      q.alg_flops = flops_total * ((double)q.M / full_M);
+      if (q.ntaps == 0) {
+        // no contributing tap (cannot happen for k >= 2): the gradient there is zero
+        continue;
+      }
+      q.K = q.ntaps * p.Cin;
+      int rc = launch_conv_tiles(q, 0, 0, 0, st);
+      if (rc != TBN_OK) return rc;
+    }
   return TBN_OK;
 }
 
@@ -511,7 +634,14 @@ size_t tbn_wgrad_workspace_floats(int M, int Cout, int Cin, int taps) {
 int tbn_launch_wgrad(WgradP p, int rowmode, float* dw, float* workspace, hipStream_t st) {
   TBN_REQUIRE(p.Cin % 4 == 0 && p.Cout % 4 == 0 && p.dy_ld % 4 == 0 && p.x_ld % 4 == 0,
               "wgrad: channel counts / pitches must be multiples of 4");
-  TBN_REQUIRE((long)p.N * p.H * p.W < (1l << 31) && p.M > 0, "wgrad: pixel count out of range");
+  TBN_REQUIRE(p.M > 0, "wgrad: empty problem");
+  {
+    const size_t xb = (size_t)p.N * p.H * p.W * (rowmode ? p.cp : p.x_ld) * sizeof(float);
+    const size_t db = (size_t)p.M * p.dy_ld * sizeof(float);
+    TBN_REQUIRE(xb < (1ull << 31) && db < (1ull << 31), "wgrad: operand extent >= 2 GiB (process the frames in chunks)");
+    p.x_bytes = (unsigned)xb;
+    p.dy_bytes = (unsigned)db;
+  }
   int mt, nt, splits, rps;
   tbn_wgrad_plan(p.M, p.Cout, p.Cin, p.taps, &mt, &nt, &splits, &rps);
   p.K = p.taps * p.Cin;

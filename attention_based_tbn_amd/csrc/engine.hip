@@ -504,6 +504,7 @@ int tbn_backbone_forward(const tbn_backbone_plan* P, int training, const float* 
         zs[i].col_begin = col;
         col += c.couts[i];
       }
+      tbn_prof_label(("fwd " + c.names[c.nparts - 1]).c_str());
       if (training) {
         float* y = ws + c.y_off;
         p.mode = CONV_EPI_STATS;
@@ -599,6 +600,7 @@ int tbn_backbone_backward(const tbn_backbone_plan* P, const float* dfeatures, co
                                        bn_grad ? g->dbeta + c.c_off : nullptr, g->dbias + c.c_off, st));
     TBN_TRY(tbn_launch_bn_bwd_apply(dz, c.nparts, y, M, c.cout, scale + c.c_off, shift + c.c_off, coef, y, st));
     // weight gradient
+    tbn_prof_label(("wgrad " + c.names[c.nparts - 1]).c_str());
     {
       WgradP wp;
       memset(&wp, 0, sizeof(wp));
@@ -634,6 +636,7 @@ int tbn_backbone_backward(const tbn_backbone_plan* P, const float* dfeatures, co
     }
     // data gradient: conv of dy with flipped / transposed weights (zero-insertion for stride 2)
     if (c.need_dgrad) {
+      tbn_prof_label(("dgrad " + c.names[c.nparts - 1]).c_str());
       float* wt = ws + P->wt_off;
       TBN_TRY(tbn_launch_weight_flip_transpose(prm->weight + c.w_off, wt, c.cout, c.k * c.k, c.cin, st));
       ConvP p;

@@ -15,16 +15,26 @@ struct ConvP {
   Seg seg[3];
   int nseg;
   int in_ld;
+  // ---- caller-facing geometry (host side fills the derived fields below from these)
   int N, H, W;            // input spatial dims (for dgrad: dims of dy)
-  int OH, OW;
+  int OH, OW;             // full output dims
   int Cin;                // K per tap (ROWMODE: padded filter-row length in floats)
   int Cout;
   int R, S, stride, pad, up;
-  int M, K;
+  int M, K;               // GEMM M (output pixels of this launch) and reduction length of this launch
   int cp;                 // ROWMODE: channels per pixel of the padded NHWC input
   int tiles_m, tiles_n;
   int mode, flags;
   double alg_flops;       // host only: algorithmic FLOPs of this launch (profiling)
+  // ---- derived by tbn_launch_conv
+  unsigned in_bytes, wt_bytes;          // buffer extents: out-of-range lanes read zeros (hardware check)
+  int OHs, OWs;                         // output sub-grid this launch covers (m -> n, a, b)
+  int out_sy, out_oy, out_sx, out_ox;   // full-grid output pixel = (a*out_sy+out_oy, b*out_sx+out_ox)
+  int in_sy, in_sx;                     // input step per sub-grid step
+  int Krow;                             // floats per weight row (all taps)
+  int ntaps;
+  short tap_dy[9], tap_dx[9];           // input offset of tap t (padding folded in)
+  int tap_koff[9];                      // float offset of tap t inside a weight row
 };
 
 struct WgradP {
@@ -42,11 +52,13 @@ struct WgradP {
   int rows_per_split;
   FastDiv div_ohw, div_ow;
   double alg_flops;       // host only
+  unsigned dy_bytes, x_bytes;
 };
 
 // optional in-process profiler: brackets every conv-GEMM launch with hipEvents on its stream
 void tbn_prof_begin(const char* kernel, double flops, hipStream_t st);
 void tbn_prof_end(hipStream_t st);
+void tbn_prof_label(const char* label);
 
 // conv_igemm.hip
 void tbn_conv_pick_tile(int M, int Cout, int K, int* mt, int* nt);

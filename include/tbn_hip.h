@@ -34,7 +34,8 @@ const char* tbn_last_error(void);
  * weight-grad implicit GEMMs) is bracketed by hipEvents recorded on the launch stream; entries
  * aggregate, per kernel instantiation, the launch count, summed event time and summed algorithmic
  * FLOPs (2*M*Cout*R*S*Cin of the convolution; padding / zero-insertion work is not counted).
- * tbn_profile_num_entries() synchronises the recorded events. */
+ * tbn_profile_num_entries() synchronises the recorded events.  enable(2) keys entries per layer
+ * ("kernel | fwd/dgrad/wgrad <conv name>") instead of per kernel instantiation. */
 int tbn_profile_enable(int on);
 int tbn_profile_reset(void);
 int tbn_profile_num_entries(void);
