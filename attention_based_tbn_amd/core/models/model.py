@@ -55,6 +55,11 @@ class TBNModel(nn.Module):
         self.attention_type = cfg.model.attention.type
         self.device = device
         self._pretrained_state = pretrained_state
+        # MI355X: the per-modality backbones are independent until the fusion -> run them on
+        # separate HIP streams so small-grid layers of one backbone fill CUs another leaves idle
+        # (autograd replays each backward on its forward stream, so backward overlaps as well)
+        self.multi_stream = True
+        self._streams = {}
         if cfg.model.agg_type.lower() == "avg":
             self.agg_type = "avg"
         else:
@@ -126,18 +131,42 @@ class TBNModel(nn.Module):
             return scores
         return ops.segment_mean(scores, b, n)
 
+    def _run_backbones(self, input):
+        """raw backbone outputs per modality: (R,1024), or (R,T,1024) for attended audio"""
+        def run(m):
+            b, n, c, h, w = input[m].shape
+            base = getattr(self, "Base_{}".format(m))
+            x = input[m].reshape(b * n, c, h, w)
+            return base.forward_sequence(x) if (m == "Audio" and self.use_attention) else base(x)
+
+        first = input[self.modality[0]]
+        if not (self.multi_stream and first.is_cuda and len(self.modality) > 1):
+            return {m: run(m) for m in self.modality}
+        main = torch.cuda.current_stream()
+        raw = {}
+        for m in self.modality:
+            st = self._streams.get(m)
+            if st is None or st.device != first.device:
+                st = self._streams[m] = torch.cuda.Stream(device=first.device)
+            st.wait_stream(main)
+            with torch.cuda.stream(st):
+                raw[m] = run(m)
+        for m in self.modality:
+            main.wait_stream(self._streams[m])
+            raw[m].record_stream(main)
+        return raw
+
     def forward(self, input):
         features = []
         att_wts = None
         att = self.cfg.model.attention
+        raw_all = self._run_backbones(input)
         for m_no, m in enumerate(self.modality):
             b, n, c, h, w = input[m].shape
-            base_model = getattr(self, "Base_{}".format(m))
-            x = input[m].reshape(b * n, c, h, w)
             if m == "Audio":
                 # the backbone always runs (BN running statistics advance even when the audio
                 # feature is then dropped), exactly like reference model.py:214-222
-                raw = base_model.forward_sequence(x) if self.use_attention else base_model(x)
+                raw = raw_all[m]
                 if (self.training and len(self.modality) > 1 and self.cfg.data.audio.dropout > 0
                         and np.random.uniform() > self.cfg.data.audio.dropout):
                     feature = torch.zeros_like(features[0])
@@ -158,7 +187,7 @@ class TBNModel(nn.Module):
                     feature = feature.repeat(new_size, 1)
                     n *= new_size
             else:
-                feature = base_model(x)
+                feature = raw_all[m]
             features.extend([feature])
         features = torch.cat(features, dim=1) if len(features) > 1 else features[0]
 

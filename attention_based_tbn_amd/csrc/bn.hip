@@ -13,7 +13,7 @@
 #include "tbn_kernels.h"
 
 static inline int pick_chunk(int P, int rp) {
-  int pch = cdiv(P, 1024);
+  int pch = cdiv(P, 512);
   if (pch < 64) pch = 64;
   return cdiv(pch, rp) * rp;
 }
@@ -69,12 +69,13 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
                                                           float* running_var, float momentum, float eps,
                                                           float* save_mean, float* save_rstd, float* scale,
                                                           float* shift) {
-  __shared__ double red[2][8][32];
-  const int tid = threadIdx.x, cl = tid & 31, slot = tid >> 5;
-  const int c = blockIdx.x * 32 + cl;
+  // 8 channels per workgroup, 32 slots per channel: short dependent chains, fixed summation order
+  __shared__ double red[2][32][8];
+  const int tid = threadIdx.x, cl = tid & 7, slot = tid >> 3;
+  const int c = blockIdx.x * 8 + cl;
   double a = 0.0, b = 0.0;
   if (c < C)
-    for (int i = slot; i < nparts; i += 8) {
+    for (int i = slot; i < nparts; i += 32) {
       a += (double)partial[((size_t)i * 2 + 0) * C + c];
       b += (double)partial[((size_t)i * 2 + 1) * C + c];
     }
@@ -83,7 +84,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
   __syncthreads();
   if (slot == 0 && c < C) {
     double s1 = 0.0, s2 = 0.0;
-    for (int k = 0; k < 8; ++k) {
+    for (int k = 0; k < 32; ++k) {
       s1 += red[0][k][cl];
       s2 += red[1][k][cl];
     }
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
 int tbn_launch_bn_finalize(const float* partial, int nparts, int P, int C, const float* gamma, const float* beta,
                            float* running_mean, float* running_var, float momentum, float eps, float* save_mean,
                            float* save_rstd, float* scale, float* shift, hipStream_t st) {
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 32)), dim3(256), 0, st, partial, nparts, P, C, gamma, beta,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 8)), dim3(256), 0, st, partial, nparts, P, C, gamma, beta,
                      running_mean, running_var, momentum, eps, save_mean, save_rstd, scale, shift);
   TBN_CHECK_LAUNCH("bn_finalize");
   return TBN_OK;
@@ -265,12 +266,12 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
                                                               const float* __restrict__ mean,
                                                               const float* __restrict__ rstd, float* coef,
                                                               float* dgamma, float* dbeta, float* dbias) {
-  __shared__ double red[2][8][32];
-  const int tid = threadIdx.x, cl = tid & 31, slot = tid >> 5;
-  const int c = blockIdx.x * 32 + cl;
+  __shared__ double red[2][32][8];
+  const int tid = threadIdx.x, cl = tid & 7, slot = tid >> 3;
+  const int c = blockIdx.x * 8 + cl;
   double a = 0.0, b = 0.0;
   if (c < C)
-    for (int i = slot; i < nparts; i += 8) {
+    for (int i = slot; i < nparts; i += 32) {
       a += (double)partial[((size_t)i * 2 + 0) * C + c];
       b += (double)partial[((size_t)i * 2 + 1) * C + c];
     }
@@ -279,7 +280,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
   __syncthreads();
   if (slot == 0 && c < C) {
     double s1 = 0.0, s2 = 0.0;
-    for (int k = 0; k < 8; ++k) {
+    for (int k = 0; k < 32; ++k) {
       s1 += red[0][k][cl];
       s2 += red[1][k][cl];
     }
@@ -298,7 +299,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
 int tbn_launch_bn_bwd_finalize(const float* partial, int nparts, int P, int C, const float* scale, const float* mean,
                                const float* rstd, float* coef, float* dgamma, float* dbeta, float* dbias,
                                hipStream_t st) {
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 32)), dim3(256), 0, st, partial, nparts, P, C, scale, mean,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 8)), dim3(256), 0, st, partial, nparts, P, C, scale, mean,
                      rstd, coef, dgamma, dbeta, dbias);
   TBN_CHECK_LAUNCH("bn_bwd_finalize");
   return TBN_OK;

@@ -170,15 +170,22 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
   for (int ks = 0; ks < ksteps; ++ks) {
     const bool more = (ks + 1 < ksteps);
     if (more) load_tiles(ks + 1);  // global loads stay in flight under the MFMA phase
-#pragma unroll
-    for (int kg = 0; kg < 4; ++kg) {
-      float4 a[MT], b[NT];
+    float4 fa[2][MT], fb[2][NT];
+    auto frag_load = [&](int buf, int kg) {
 #pragma unroll
       for (int i = 0; i < MT; ++i)
-        a[i] = *reinterpret_cast<const float4*>(&As[(wave * 32 * MT + i * 32 + lrow) * LDT + kg * 8 + lhalf * 4]);
+        fa[buf][i] =
+            *reinterpret_cast<const float4*>(&As[(wave * 32 * MT + i * 32 + lrow) * LDT + kg * 8 + lhalf * 4]);
 #pragma unroll
       for (int j = 0; j < NT; ++j)
-        b[j] = *reinterpret_cast<const float4*>(&Bs[(j * 32 + lrow) * LDT + kg * 8 + lhalf * 4]);
+        fb[buf][j] = *reinterpret_cast<const float4*>(&Bs[(j * 32 + lrow) * LDT + kg * 8 + lhalf * 4]);
+    };
+    frag_load(0, 0);
+#pragma unroll
+    for (int kg = 0; kg < 4; ++kg) {
+      if (kg < 3) frag_load((kg + 1) & 1, kg + 1);
+      const float4* a = fa[kg & 1];
+      const float4* b = fb[kg & 1];
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         if (j < nt_act) {
