@@ -47,6 +47,7 @@ SIGNATURES = {
                                        C.POINTER(c_i), C.POINTER(c_i)]),
     "tbn_backbone_forward": (c_i, [C.c_void_p, c_i, c_fp, C.POINTER(BackboneParams), c_fp, c_sz,
                                    C.POINTER(C.c_void_p), c_fp]),
+    "tbn_backbone_autotune": (c_i, [C.c_void_p, c_i, C.POINTER(BackboneParams), c_fp, c_sz, c_fp]),
     "tbn_backbone_backward": (c_i, [C.c_void_p, c_fp, C.POINTER(BackboneParams), C.POINTER(BackboneGrads), c_fp,
                                     c_sz, c_fp]),
     "tbn_conv2d_fwd": (c_i, [c_fp, c_i, c_fp, c_fp, c_fp, c_i] + [c_i] * 10 + [c_fp, c_fp, c_fp, c_fp]),

@@ -52,6 +52,7 @@ class _Plan:
         call("tbn_backbone_out_shape", self.handle, C.byref(oh), C.byref(ow), C.byref(oc))
         self.out_shape = (frames, oh.value, ow.value, oc.value)
         self.pool = []  # [tensor, weakref-to-token or None]
+        self.tuned = {True: False, False: False}   # per mode (training / eval)
 
     def workspace(self, training, device, token=None):
         need = lib().tbn_backbone_workspace_bytes(self.handle, int(training))
@@ -92,6 +93,16 @@ class _BackboneFn(torch.autograd.Function):
                              ptr(module.running_var), 0.1, 1e-5)
         feat_ptr = C.c_void_p()
         st = stream_ptr()
+        if module.autotune and not plan.tuned[training]:
+            # first use of this (shape, mode): run once so every buffer holds real data, time the tile
+            # candidates of each layer on it, then do the real forward below with the tuned plan
+            saved = (module.running_mean.clone(), module.running_var.clone())
+            call("tbn_backbone_forward", plan.handle, int(training), ptr(x), C.byref(prm), ptr(ws), ws.numel(),
+                 C.byref(feat_ptr), st)
+            call("tbn_backbone_autotune", plan.handle, int(training), C.byref(prm), ptr(ws), ws.numel(), st)
+            module.running_mean.copy_(saved[0])
+            module.running_var.copy_(saved[1])
+            plan.tuned[training] = True
         call("tbn_backbone_forward", plan.handle, int(training), ptr(x), C.byref(prm), ptr(ws), ws.numel(),
              C.byref(feat_ptr), st)
         N, H, W, Cc = plan.out_shape
@@ -144,6 +155,7 @@ class BNInception(nn.Module):
         self.attend = False
         self.feature_size = 1024
         self.eval_chunk = 256       # frames per engine call in eval mode (bounds the workspace)
+        self.autotune = True        # time the GEMM tile candidates per layer on first use of a shape
         self._plans = OrderedDict()
         # layer table from the engine (needs the library, not a GPU)
         probe = C.c_void_p()

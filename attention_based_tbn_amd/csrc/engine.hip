@@ -293,7 +293,7 @@ void plan_memory(tbn_backbone_plan* P) {
     const int M = (int)(R * c.outH * c.outW);
     const int K = c.stem ? 7 * P->kw : c.k * c.k * c.cin;
     tbn_conv_pick_tile(M, c.cout, K, &c.mt, &c.nt);
-    size_t a = (size_t)cdiv(M, 128 * c.mt) * 2 * c.cout;
+    size_t a = (size_t)cdiv(M, 128) * 2 * c.cout;  // worst case (mt = 1): autotune may pick any tile
     size_t bparts = (size_t)tbn_bn_bwd_parts(M, c.cout) * 2 * c.cout;
     if (a > partial) partial = a;
     if (bparts > partial) partial = bparts;
@@ -542,6 +542,126 @@ int tbn_backbone_forward(const tbn_backbone_plan* P, int training, const float* 
   }
   *features_out = ws + P->bufs[P->out_buf].off;
   return TBN_OK;
+}
+
+// One-time tile autotuning: times every (MT, NT) tile of the forward and data-gradient implicit GEMM
+// of each layer on the real shapes (2 launches each, hipEvents) and stores the fastest in the plan.
+// Synchronises the stream (the only entry point that does); activations in `workspace` are clobbered.
+int tbn_backbone_autotune(tbn_backbone_plan* P, int training, const tbn_backbone_params* prm, void* workspace,
+                          size_t workspace_bytes, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  TBN_REQUIRE(P && prm && workspace, "autotune: null argument");
+  TBN_REQUIRE(workspace_bytes >= tbn_backbone_workspace_bytes(P, training), "autotune: workspace too small");
+  float* ws = (float*)workspace;
+  const int R = P->frames;
+  float* scale = ws + P->stats_off + 2 * P->chan_floats;
+  float* shift = scale + P->chan_floats;
+  hipEvent_t e0, e1;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
+    tbn_set_error("autotune: hipEventCreate failed");
+    return TBN_ERR_LAUNCH;
+  }
+  int rc = TBN_OK;
+  for (auto& c : P->convs) {
+    const Buf& ib = P->bufs[c.inbuf];
+    for (int pass = 0; pass < 2 && rc == TBN_OK; ++pass) {  // 0: forward, 1: data gradient
+      if (pass == 1 && (!training || !c.need_dgrad || c.stride != 1)) continue;
+      ConvP p;
+      memset(&p, 0, sizeof(p));
+      p.N = R;
+      p.up = 1;
+      p.nseg = 1;
+      if (pass == 0) {
+        p.in = ws + ib.off;
+        p.in_ld = ib.C;
+        p.H = c.inH;
+        p.W = c.inW;
+        p.OH = c.outH;
+        p.OW = c.outW;
+        p.Cout = c.cout;
+        p.stride = c.stride;
+        p.pad = c.pad;
+        p.M = R * c.outH * c.outW;
+        p.bias = prm->bias + c.c_off;
+        if (c.stem) {
+          p.wt = ws + P->wpack_off;
+          p.Cin = P->kw;
+          p.R = 7;
+          p.S = 1;
+          p.K = 7 * P->kw;
+          p.cp = P->cp;
+        } else {
+          p.wt = prm->weight + c.w_off;
+          p.Cin = c.cin;
+          p.R = p.S = c.k;
+          p.K = c.k * c.k * c.cin;
+        }
+        p.mode = training ? CONV_EPI_STATS : CONV_EPI_EVAL;
+        p.scale = scale + c.c_off;
+        p.shift = shift + c.c_off;
+        p.stat_partial = ws + P->partial_off;
+        // write into the layer's own y buffer (training) or its first destination (eval)
+        if (training) {
+          p.seg[0].ptr = ws + c.y_off;
+          p.seg[0].ld = c.cout;
+        } else {
+          const Buf& db = P->bufs[c.dst_buf[0]];
+          p.seg[0].ptr = ws + db.off + c.dst_choff[0];
+          p.seg[0].ld = db.C;
+          p.Cout = c.couts[0];  // eval tuning on the first fused part only keeps all writes in range
+          if (c.nparts > 1) continue;
+        }
+      } else {
+        p.in = ws + c.y_off;
+        p.in_ld = c.cout;
+        p.wt = ws + P->wt_off;
+        p.H = c.outH;
+        p.W = c.outW;
+        p.OH = c.inH;
+        p.OW = c.inW;
+        p.Cin = c.cout;
+        p.Cout = c.cin;
+        p.R = p.S = c.k;
+        p.stride = 1;
+        p.pad = c.k - 1 - c.pad;
+        p.M = R * c.inH * c.inW;
+        p.K = c.k * c.k * c.cout;
+        p.mode = CONV_EPI_PLAIN;
+        p.seg[0].ptr = ws + ib.doff;
+        p.seg[0].ld = ib.C;
+      }
+      float best = 1e30f;
+      int bm = 1, bn = 1;
+      for (int mt = 1; mt <= 2 && rc == TBN_OK; ++mt)
+        for (int nt = 1; nt <= 4 && rc == TBN_OK; ++nt) {
+          if (32 * (nt - 1) >= p.Cout) continue;
+          float ms = 0.f;
+          for (int rep = 0; rep < 2 && rc == TBN_OK; ++rep) {
+            hipEventRecord(e0, st);
+            rc = tbn_launch_conv(p, c.stem && pass == 0, mt, nt, st);
+            hipEventRecord(e1, st);
+            hipEventSynchronize(e1);
+            hipEventElapsedTime(&ms, e0, e1);
+          }
+          if (ms < best) {
+            best = ms;
+            bm = mt;
+            bn = nt;
+          }
+        }
+      if (pass == 0) {
+        c.mt = bm;
+        c.nt = bn;
+      } else {
+        c.d_mt = bm;
+        c.d_nt = bn;
+      }
+    }
+    if (rc != TBN_OK) break;
+  }
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  return rc;
 }
 
 int tbn_backbone_backward(const tbn_backbone_plan* P, const float* dfeatures, const tbn_backbone_params* prm,

@@ -94,6 +94,11 @@ int tbn_backbone_tensor_info(const tbn_backbone_plan* plan, const char* conv_nam
 int tbn_backbone_forward(const tbn_backbone_plan* plan, int training, const float* x_nchw,
                          const tbn_backbone_params* params, void* workspace, size_t workspace_bytes,
                          float** features_out, void* stream);
+/* optional one-time tuning of the per-layer GEMM tiles on the real shapes (times each candidate with
+ * hipEvents).  The ONLY entry point that synchronises the stream; clobbers the activations held in
+ * `workspace`, so call it between steps (e.g. right after the first forward of a new plan). */
+int tbn_backbone_autotune(tbn_backbone_plan* plan, int training, const tbn_backbone_params* params, void* workspace,
+                          size_t workspace_bytes, void* stream);
 /* dfeatures: NHWC (frames, h, w, 1024) gradient of *features_out; needs the workspace of the
  * matching training forward untouched. */
 int tbn_backbone_backward(const tbn_backbone_plan* plan, const float* dfeatures,
