@@ -52,6 +52,7 @@ SIGNATURES = {
                                     c_sz, c_fp]),
     "tbn_conv2d_fwd": (c_i, [c_fp, c_i, c_fp, c_fp, c_fp, c_i] + [c_i] * 10 + [c_fp, c_fp, c_fp, c_fp]),
     "tbn_conv2d_stat_tiles": (c_i, [c_i] * 8),
+    "tbn_conv2d_fwd_tile": (c_i, [c_fp, c_i, c_fp, c_fp, c_fp, c_i] + [c_i] * 10 + [c_fp, c_i, c_i, c_fp]),
     "tbn_conv2d_dgrad": (c_i, [c_fp, c_i, c_fp, c_fp, c_i] + [c_i] * 9 + [c_fp, c_fp]),
     "tbn_conv2d_wgrad_workspace_floats": (c_sz, [c_i] * 8),
     "tbn_conv2d_wgrad": (c_i, [c_fp, c_i, c_fp, c_i, c_fp] + [c_i] * 8 + [c_fp, c_fp]),

@@ -194,6 +194,26 @@ int tbn_conv2d_fwd(const float* in, int in_ld, const float* weight, const float*
   return tbn_launch_conv(p, 0, 0, 0, (hipStream_t)stream);
 }
 
+// test / tuning aid: forward conv with an explicit (mt, nt) tile (0,0 = heuristic)
+int tbn_conv2d_fwd_tile(const float* in, int in_ld, const float* weight, const float* bias, float* out, int out_ld,
+                        int n, int h, int w, int cin, int cout, int ksize, int stride, int pad, int epilogue, int flags,
+                        float* stat_partial, int mt, int nt, void* stream) {
+  ConvP p;
+  conv_geom(&p, n, h, w, cin, cout, ksize, stride, pad);
+  p.in = in;
+  p.in_ld = in_ld;
+  p.wt = weight;
+  p.bias = bias;
+  p.stat_partial = stat_partial;
+  p.mode = epilogue;
+  p.flags = flags;
+  p.nseg = 1;
+  p.seg[0].ptr = out;
+  p.seg[0].ld = out_ld;
+  p.seg[0].col_begin = 0;
+  return tbn_launch_conv(p, 0, mt, nt, (hipStream_t)stream);
+}
+
 int tbn_conv2d_dgrad(const float* dout, int dout_ld, const float* weight, float* din, int din_ld, int n, int h, int w,
                      int cin, int cout, int ksize, int stride, int pad, int accumulate, float* workspace,
                      void* stream) {

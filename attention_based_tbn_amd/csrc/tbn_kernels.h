@@ -33,8 +33,11 @@ struct ConvP {
   int in_sy, in_sx;                     // input step per sub-grid step
   int Krow;                             // floats per weight row (all taps)
   int ntaps;
-  short tap_dy[9], tap_dx[9];           // input offset of tap t (padding folded in)
+  int tap_dy[9], tap_dx[9];             // input offset of tap t (padding folded in)
   int tap_koff[9];                      // float offset of tap t inside a weight row
+  int tap_off[9];                       // byte offset of tap t relative to the window origin pixel
+  int ty0, tny, tx0, tnx;               // the taps form a grid: tap (ry, rx) = (ty0 + ry, tx0 + rx), t = ry*tnx + rx
+  FastDiv div_ohw, div_ow;              // m -> (n, a, b) without integer division
 };
 
 struct WgradP {

@@ -115,6 +115,11 @@ int tbn_conv2d_fwd(const float* in, int in_ld, const float* weight, const float*
                    int n, int h, int w, int cin, int cout, int ksize, int stride, int pad, int epilogue, int flags,
                    const float* scale, const float* shift, float* stat_partial, void* stream);
 int tbn_conv2d_stat_tiles(int n, int h, int w, int cin, int cout, int ksize, int stride, int pad);
+/* tuning / test aid: as tbn_conv2d_fwd (epilogue 0 or 1) with an explicit tile: the workgroup computes
+ * (128*mt) x (32*nt) outputs, mt in {1,2}, nt in {1..4}; (0,0) = built-in heuristic */
+int tbn_conv2d_fwd_tile(const float* in, int in_ld, const float* weight, const float* bias, float* out, int out_ld,
+                        int n, int h, int w, int cin, int cout, int ksize, int stride, int pad, int epilogue, int flags,
+                        float* stat_partial, int mt, int nt, void* stream);
 /* data gradient: din (n,h,w,cin) = conv_transpose(dout).  workspace: cout*k*k*cin floats. */
 int tbn_conv2d_dgrad(const float* dout, int dout_ld, const float* weight, float* din, int din_ld, int n, int h, int w,
                      int cin, int cout, int ksize, int stride, int pad, int accumulate, float* workspace,
