@@ -23,7 +23,8 @@ class BackboneParams(C.Structure):
 
 
 class BackboneGrads(C.Structure):
-    _fields_ = [("dweight", c_fp), ("dbias", c_fp), ("dgamma", c_fp), ("dbeta", c_fp), ("bn_grad_layers", c_i)]
+    _fields_ = [("dweight", c_fp), ("dbias", c_fp), ("dgamma", c_fp), ("dbeta", c_fp), ("bn_grad_layers", c_i),
+                ("aux_stream", c_fp)]
 
 
 # name -> (restype, argtypes); every symbol declared in include/tbn_hip.h

@@ -135,7 +135,14 @@ class _BackboneFn(torch.autograd.Function):
         dbe = torch.zeros_like(beta) if (bn_first or bn_rest) else None
         prm = BackboneParams(ptr(weight), ptr(bias), ptr(gamma), ptr(beta), ptr(module.running_mean),
                              ptr(module.running_var), 0.1, 1e-5)
-        grads = BackboneGrads(ptr(dw), ptr(db), ptr(dg), ptr(dbe), 2 if bn_rest else (1 if bn_first else 0))
+        aux = 0
+        if module.use_aux_stream:
+            cur = torch.cuda.current_stream()
+            a = module._aux_streams.get(cur.cuda_stream)
+            if a is None:
+                a = module._aux_streams[cur.cuda_stream] = torch.cuda.Stream(device=dout.device)
+            aux = a.cuda_stream
+        grads = BackboneGrads(ptr(dw), ptr(db), ptr(dg), ptr(dbe), 2 if bn_rest else (1 if bn_first else 0), aux)
         call("tbn_backbone_backward", plan.handle, ptr(dfeat), C.byref(prm), C.byref(grads), ptr(ws), ws.numel(), st)
         ctx.token = None  # workspace may be reused now
         n0 = module.first_bn_channels
@@ -156,6 +163,8 @@ class BNInception(nn.Module):
         self.feature_size = 1024
         self.eval_chunk = 256       # frames per engine call in eval mode (bounds the workspace)
         self.autotune = True        # time the GEMM tile candidates per layer on first use of a shape
+        self.use_aux_stream = True  # weight-gradient GEMMs on a second HIP stream (overlaps dgrad / BN backward)
+        self._aux_streams = {}
         self._plans = OrderedDict()
         # layer table from the engine (needs the library, not a GPU)
         probe = C.c_void_p()

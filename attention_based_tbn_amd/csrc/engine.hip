@@ -94,6 +94,9 @@ struct tbn_backbone_plan {
   size_t partial_floats, wsplit_floats, wt_floats;
   size_t argmax_bytes_off, total_bytes_train, total_bytes_eval;
   size_t eval_floats;
+  // fork/join events for the optional aux (weight-gradient) stream; created on first use
+  hipEvent_t ev[8];
+  int n_ev = 0;
 };
 
 namespace {
@@ -356,7 +359,11 @@ int tbn_backbone_plan_create(int in_channels, int frames, int height, int width,
   return TBN_OK;
 }
 
-void tbn_backbone_plan_destroy(tbn_backbone_plan* p) { delete p; }
+void tbn_backbone_plan_destroy(tbn_backbone_plan* p) {
+  if (!p) return;
+  for (int i = 0; i < p->n_ev; ++i) (void)hipEventDestroy(p->ev[i]);
+  delete p;
+}
 
 int tbn_backbone_num_convs(const tbn_backbone_plan* P) {
   int n = 0;
@@ -667,6 +674,19 @@ int tbn_backbone_autotune(tbn_backbone_plan* P, int training, const tbn_backbone
 int tbn_backbone_backward(const tbn_backbone_plan* P, const float* dfeatures, const tbn_backbone_params* prm,
                           const tbn_backbone_grads* g, void* workspace, size_t workspace_bytes, void* stream) {
   hipStream_t st = (hipStream_t)stream;
+  hipStream_t aux = (hipStream_t)g->aux_stream;
+  tbn_backbone_plan* PM = const_cast<tbn_backbone_plan*>(P);  // event pool only
+  if (aux != nullptr && aux != st && PM->n_ev == 0) {
+    for (int i = 0; i < 8; ++i) {
+      if (hipEventCreateWithFlags(&PM->ev[i], hipEventDisableTiming) != hipSuccess) {
+        tbn_set_error("backbone_backward: hipEventCreate failed");
+        return TBN_ERR_LAUNCH;
+      }
+      PM->n_ev = i + 1;
+    }
+  }
+  if (aux == st) aux = nullptr;
+  int ev_next = 0;
   TBN_REQUIRE(P && dfeatures && prm && g && workspace, "backbone_backward: null argument");
   TBN_REQUIRE(g->dweight && g->dbias, "backbone_backward: dweight/dbias required");
   TBN_REQUIRE(workspace_bytes >= P->total_bytes_train, "backbone_backward: workspace too small");
@@ -719,8 +739,17 @@ int tbn_backbone_backward(const tbn_backbone_plan* P, const float* dfeatures, co
                                        mean + c.c_off, rstd + c.c_off, coef, bn_grad ? g->dgamma + c.c_off : nullptr,
                                        bn_grad ? g->dbeta + c.c_off : nullptr, g->dbias + c.c_off, st));
     TBN_TRY(tbn_launch_bn_bwd_apply(dz, c.nparts, y, M, c.cout, scale + c.c_off, shift + c.c_off, coef, y, st));
-    // weight gradient
+    // weight gradient -- on the aux stream when given: it only reads dy (final after bn_bwd_apply) and
+    // the layer input, so it overlaps the data-gradient / BN-backward chain that continues on `st`
     tbn_prof_label(("wgrad " + c.names[c.nparts - 1]).c_str());
+    hipStream_t wst = st;
+    if (aux != nullptr) {
+      hipEvent_t e = PM->ev[ev_next];
+      ev_next = (ev_next + 1) & 7;
+      (void)hipEventRecord(e, st);
+      (void)hipStreamWaitEvent(aux, e, 0);
+      wst = aux;
+    }
     {
       WgradP wp;
       memset(&wp, 0, sizeof(wp));
@@ -745,13 +774,13 @@ int tbn_backbone_backward(const tbn_backbone_plan* P, const float* dfeatures, co
         wp.taps = 7;
         wp.cp = P->cp;
         float* dwp = ws + P->dwpack_off;
-        TBN_TRY(tbn_launch_wgrad(wp, 1, dwp, ws + P->wsplit_off, st));
-        TBN_TRY(tbn_launch_unpack_stem_wgrad(dwp, g->dweight + c.w_off, 64, P->cin0, P->cp, P->kw, st));
+        TBN_TRY(tbn_launch_wgrad(wp, 1, dwp, ws + P->wsplit_off, wst));
+        TBN_TRY(tbn_launch_unpack_stem_wgrad(dwp, g->dweight + c.w_off, 64, P->cin0, P->cp, P->kw, wst));
       } else {
         wp.Cin = c.cin;
         wp.R = wp.S = c.k;
         wp.taps = c.k * c.k;
-        TBN_TRY(tbn_launch_wgrad(wp, 0, g->dweight + c.w_off, ws + P->wsplit_off, st));
+        TBN_TRY(tbn_launch_wgrad(wp, 0, g->dweight + c.w_off, ws + P->wsplit_off, wst));
       }
     }
     // data gradient: conv of dy with flipped / transposed weights (zero-insertion for stride 2)
@@ -786,6 +815,11 @@ int tbn_backbone_backward(const tbn_backbone_plan* P, const float* dfeatures, co
       p.seg[0].col_begin = 0;
       TBN_TRY(tbn_launch_conv(p, 0, c.d_mt, c.d_nt, st));
     }
+  }
+  if (aux != nullptr) {  // join: everything the caller enqueues on `st` next sees the weight gradients
+    hipEvent_t e = PM->ev[ev_next];
+    (void)hipEventRecord(e, aux);
+    (void)hipStreamWaitEvent(st, e, 0);
   }
   return TBN_OK;
 }

@@ -92,11 +92,11 @@ def cpu_baseline(seconds_budget=25.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch-per-gpu", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--profile-every", type=int, default=10, help="bracket conv-GEMM launches with HIP events on every k-th timed step")
+    ap.add_argument("--profile-every", type=int, default=20, help="bracket conv-GEMM launches with HIP events on every k-th timed step")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -119,6 +119,7 @@ def main():
     model, criterion, _ = build_model(cfg, modality, device)
     model.train()
     core = getattr(model, "module", model)
+    bases = [getattr(core, "Base_" + m) for m in modality]
     params = [p for p in model.parameters() if p.requires_grad]
     opt = torch.optim.SGD(params, lr=cfg.train.optim.lr, momentum=cfg.train.optim.momentum,
                           weight_decay=cfg.train.optim.weight_decay)
@@ -152,11 +153,15 @@ def main():
             # HIP-event brackets around every conv-GEMM launch; on these steps the three backbones run
             # on ONE stream so a bracket times exactly one kernel (on the other steps they overlap)
             core.multi_stream = False
+            for b_ in bases:
+                b_.use_aux_stream = False
             L.tbn_profile_enable(1)
         loss = step()
         if prof:
             L.tbn_profile_enable(0)
             core.multi_stream = True
+            for b_ in bases:
+                b_.use_aux_stream = True
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
