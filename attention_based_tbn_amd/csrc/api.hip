@@ -312,7 +312,7 @@ int tbn_bn_relu_train_fwd(const float* y, int p, int c, const float* gamma, cons
   hipStream_t st = (hipStream_t)stream;
   int parts = 0;
   TBN_TRY(tbn_launch_bn_stats(y, c, p, c, workspace, &parts, st));
-  TBN_TRY(tbn_launch_bn_finalize(workspace, parts, p, c, gamma, beta, running_mean, running_var, momentum, eps,
+  TBN_TRY(tbn_launch_bn_finalize(workspace, parts, p, c, gamma, beta, nullptr, running_mean, running_var, momentum, eps,
                                  save_mean, save_rstd, scale, shift, st));
   Seg s;
   s.ptr = z;

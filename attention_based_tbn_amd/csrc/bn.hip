@@ -65,7 +65,8 @@ int tbn_launch_bn_stats(const float* y, int ld, int P, int C, float* partial, in
 // ---------------------------------------------------------------- finalize: partials -> mean/rstd/scale/shift
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partial, int nparts, int P, int C,
                                                           const float* __restrict__ gamma,
-                                                          const float* __restrict__ beta, float* running_mean,
+                                                          const float* __restrict__ beta,
+                                                          const float* __restrict__ conv_bias, float* running_mean,
                                                           float* running_var, float momentum, float eps,
                                                           float* save_mean, float* save_rstd, float* scale,
                                                           float* shift) {
@@ -99,17 +100,19 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     shift[c] = fmaf(-(float)mean, sc, beta[c]);
     if (running_mean != nullptr) {
       const double unb = P > 1 ? var * ((double)P / (double)(P - 1)) : var;
-      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+      // the statistics are those of the bias-free conv output; the reference's BN sees conv + bias
+      const float mean_b = (float)mean + (conv_bias != nullptr ? conv_bias[c] : 0.f);
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean_b;
       running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
     }
   }
 }
 
 int tbn_launch_bn_finalize(const float* partial, int nparts, int P, int C, const float* gamma, const float* beta,
-                           float* running_mean, float* running_var, float momentum, float eps, float* save_mean,
-                           float* save_rstd, float* scale, float* shift, hipStream_t st) {
+                           const float* conv_bias, float* running_mean, float* running_var, float momentum, float eps,
+                           float* save_mean, float* save_rstd, float* scale, float* shift, hipStream_t st) {
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 8)), dim3(256), 0, st, partial, nparts, P, C, gamma, beta,
-                     running_mean, running_var, momentum, eps, save_mean, save_rstd, scale, shift);
+                     conv_bias, running_mean, running_var, momentum, eps, save_mean, save_rstd, scale, shift);
   TBN_CHECK_LAUNCH("bn_finalize");
   return TBN_OK;
 }
@@ -166,21 +169,22 @@ int tbn_launch_bn_apply(const float* y, int P, int C, const float* scale, const 
 }
 
 // ---------------------------------------------------------------- eval fold: running stats -> scale/shift
-__global__ void bn_fold_kernel(const float* gamma, const float* beta, const float* mean, const float* var, float eps,
-                               float* scale, float* shift, int C) {
+// scale = gamma / sqrt(var + eps);  shift = beta + (conv_bias - mean) * scale   (the conv epilogue
+// then computes relu(acc * scale + shift) on the bias-free accumulator)
+__global__ void bn_fold_kernel(const float* gamma, const float* beta, const float* mean, const float* var,
+                               const float* bias, float eps, float* scale, float* shift, int C) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c < C) {
     const float sc = gamma[c] / sqrtf(var[c] + eps);
     scale[c] = sc;
-    shift[c] = fmaf(-mean[c], sc, beta[c]);
+    shift[c] = fmaf((bias != nullptr ? bias[c] : 0.f) - mean[c], sc, beta[c]);
   }
 }
 
 int tbn_launch_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var, const float* bias,
                        float eps, float* scale, float* shift, int C, hipStream_t st) {
-  (void)bias;  // the conv epilogue adds the conv bias before the folded affine
-  hipLaunchKernelGGL(bn_fold_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, gamma, beta, mean, var, eps, scale, shift,
-                     C);
+  hipLaunchKernelGGL(bn_fold_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, gamma, beta, mean, var, bias, eps, scale,
+                     shift, C);
   TBN_CHECK_LAUNCH("bn_fold");
   return TBN_OK;
 }

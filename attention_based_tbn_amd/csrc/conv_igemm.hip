@@ -54,6 +54,11 @@ __device__ __forceinline__ i32x4 make_rsrc(const void* ptr, unsigned bytes) {
   return r;
 }
 
+__device__ void tbn_llvm_buffer_store_f32(float data, i32x4 srsrc, int voffset, int soffset, int aux) __asm(
+    "llvm.amdgcn.raw.buffer.store.f32");
+__device__ float tbn_llvm_buffer_load_f32(i32x4 srsrc, int voffset, int soffset, int aux) __asm(
+    "llvm.amdgcn.raw.buffer.load.f32");
+
 __device__ __forceinline__ float4 buf_load4(i32x4 r, unsigned voff, unsigned soff = 0u) {
   const f32x4 v = tbn_llvm_buffer_load_f32x4(r, (int)voff, (int)soff, 0);
   return make_float4(v.x, v.y, v.z, v.w);
@@ -244,11 +249,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
     if (!(p.flags & 64)) __syncthreads();   // flag 64: ablation, no barrier
   }
 
-  if (p.flags & 512) {  // ablation: exit before the epilogue
-    if (acc[0][0][0] == 12345.678f) p.seg[0].ptr[0] = 1.f;
-    return;
-  }
   // ---------------------------------------------------------------- epilogue
+  // EPI 1 / 2 work on the bias-free accumulator (training: a per-channel constant cancels in the batch-stat
+  // BN; eval: the bias is folded into `shift`).  Rows >= M and columns >= Cout hold exact zeros, so the
+  // statistics need no masking.  Stores are buffer stores: the lane offset is computed once per 32x32
+  // sub-tile, the per-register row step rides in the scalar offset -> no VALU address math, no branches.
   float* red = lds;  // [2][4 waves][BN] for the BN-statistics partials (tiles are dead now)
   const int mrow0 = m0 + wave * 32 * MT + 4 * lhalf;  // + i*32 + 8*g + q  (accumulator register e = 4*g + q)
   const bool tile_full = (m0 + BM <= p.M);
@@ -262,9 +267,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
     int sg = 0;
     if (p.nseg > 1 && colb >= p.seg[1].col_begin) sg = 1;
     if (p.nseg > 2 && colb >= p.seg[2].col_begin) sg = 2;
-    float* obase = p.seg[sg].ptr + (col - p.seg[sg].col_begin);
     const int old = p.seg[sg].ld;
-    const float bias = (p.bias != nullptr && col_ok) ? p.bias[col] : 0.f;
+    const i32x4 o_rsrc = make_rsrc(p.seg[sg].ptr, p.seg_bytes[sg]);
+    const unsigned col_off = (unsigned)(col - p.seg[sg].col_begin) * 4u;
+    const float bias = (EPI == 0 || EPI == 3) ? ((p.bias != nullptr && col_ok) ? p.bias[col] : 0.f) : 0.f;
     float sc = 1.f, sh = 0.f;
     if (EPI == 2 && col_ok) {
       sc = p.scale[col];
@@ -273,31 +279,37 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
-      float* rowp = obase + (size_t)(mrow0 + i * 32) * old;
+      const unsigned vbase = col_ok ? (unsigned)(mrow0 + i * 32) * (unsigned)old * 4u + col_off : TBN_OOB;
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int dm = 8 * (e >> 2) + (e & 3);
-        const int m = mrow0 + i * 32 + dm;
-        float v = acc[i][j][e] + bias;
-        if ((tile_full || m < p.M) && col_ok) {
-          float* o = rowp + dm * old;
-          if (scatter) {
-            const int ohw = p.OHs * p.OWs;
-            const int n = m / ohw, rem = m - n * ohw;
-            const int a = rem / p.OWs, b = rem - a * p.OWs;
-            o = obase + (((size_t)n * p.OH + (a * p.out_sy + p.out_oy)) * p.OW + (b * p.out_sx + p.out_ox)) * old;
-          }
-          if (EPI == 2) {
-            v = fmaxf(fmaf(v, sc, sh), 0.f);
-          } else if (EPI == 1) {
-            s1 += v;
-            s2 = fmaf(v, v, s2);
-          } else {
-            if (p.flags & CONV_FLAG_ACCUM) v += *o;
-            if (p.flags & CONV_FLAG_RELU) v = fmaxf(v, 0.f);
-          }
-          *o = v;
+        float v = acc[i][j][e];
+        if (EPI == 1) {
+          s1 += v;
+          s2 = fmaf(v, v, s2);
+        } else if (EPI == 2) {
+          v = fmaxf(fmaf(v, sc, sh), 0.f);
+        } else {
+          v += bias;
         }
+        unsigned voff = vbase, soff = (unsigned)(dm * old) * 4u;
+        if (scatter) {
+          const int m = mrow0 + i * 32 + dm;
+          const int ohw = p.OHs * p.OWs;
+          const int n = m / ohw, rem = m - n * ohw;
+          const int a = rem / p.OWs, b = rem - a * p.OWs;
+          const unsigned opix = (unsigned)((n * p.OH + (a * p.out_sy + p.out_oy)) * p.OW + (b * p.out_sx + p.out_ox));
+          voff = (m < p.M && col_ok) ? opix * (unsigned)old * 4u + col_off : TBN_OOB;
+          soff = 0u;
+        } else if (!tile_full) {
+          const int m = mrow0 + i * 32 + dm;
+          voff = (m < p.M) ? vbase : TBN_OOB;  // the scalar offset is not bounds-checked: mask the row here
+        }
+        if (EPI == 0 || EPI == 3) {
+          if (p.flags & CONV_FLAG_ACCUM) v += tbn_llvm_buffer_load_f32(o_rsrc, (int)voff, (int)soff, 0);
+          if (p.flags & CONV_FLAG_RELU) v = fmaxf(v, 0.f);
+        }
+        tbn_llvm_buffer_store_f32(v, o_rsrc, (int)voff, (int)soff, 0);
       }
     }
     if (EPI == 1) {
@@ -593,6 +605,12 @@ int tbn_launch_conv(ConvP p, int rowmode, int mt, int nt, hipStream_t st) {
   TBN_REQUIRE(in_bytes < (1ull << 31), "conv: input extent %zu B >= 2 GiB (process the frames in chunks)", in_bytes);
   p.in_bytes = (unsigned)in_bytes;
   if (p.alg_flops <= 0.0) p.alg_flops = 2.0 * p.M * (double)p.Cout * p.K;
+  for (int i = 0; i < p.nseg; ++i) {
+    const int cols = (i + 1 < p.nseg ? p.seg[i + 1].col_begin : p.Cout) - p.seg[i].col_begin;
+    const size_t ob = (((size_t)p.N * p.OH * p.OW - 1) * p.seg[i].ld + cols) * sizeof(float);
+    TBN_REQUIRE(ob < (1ull << 31) && p.seg[i].ld % 1 == 0, "conv: output extent %zu B >= 2 GiB (process the frames in chunks)", ob);
+    p.seg_bytes[i] = (unsigned)ob;
+  }
   const int taps_full = rowmode ? p.R : p.R * p.S;
   p.Krow = taps_full * p.Cin;
   p.wt_bytes = (unsigned)((size_t)p.Cout * p.Krow * sizeof(float));

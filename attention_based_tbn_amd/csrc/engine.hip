@@ -466,7 +466,7 @@ int tbn_backbone_forward(const tbn_backbone_plan* P, int training, const float* 
   TBN_TRY(tbn_launch_nchw_to_nhwc_pad(x_nchw, ws + P->x0_off, R, P->cin0, P->H, P->W, P->cp, st));
   TBN_TRY(tbn_launch_pack_stem_weight(prm->weight + P->convs[0].w_off, wpack, 64, P->cin0, P->cp, P->kw, st));
   if (!training)
-    TBN_TRY(tbn_launch_bn_fold(prm->gamma, prm->beta, prm->running_mean, prm->running_var, nullptr, prm->eps, scale,
+    TBN_TRY(tbn_launch_bn_fold(prm->gamma, prm->beta, prm->running_mean, prm->running_var, prm->bias, prm->eps, scale,
                                shift, (int)P->chan_floats, st));
 
   for (const Op& o : P->ops) {
@@ -487,7 +487,7 @@ int tbn_backbone_forward(const tbn_backbone_plan* P, int training, const float* 
       p.pad = c.pad;
       p.up = 1;
       p.M = R * c.outH * c.outW;
-      p.bias = prm->bias + c.c_off;
+      p.bias = nullptr;  // training: cancels in the batch-stat BN (finalize adds it to running_mean); eval: folded into shift
       p.alg_flops = 2.0 * p.M * (double)c.cout * c.k * c.k * c.cin;
       if (c.stem) {
         p.wt = wpack;
@@ -522,7 +522,8 @@ int tbn_backbone_forward(const tbn_backbone_plan* P, int training, const float* 
         p.stat_partial = ws + P->partial_off;
         TBN_TRY(tbn_launch_conv(p, c.stem, c.mt, c.nt, st));
         TBN_TRY(tbn_launch_bn_finalize(ws + P->partial_off, cdiv(p.M, 128 * c.mt), p.M, c.cout, prm->gamma + c.c_off,
-                                       prm->beta + c.c_off, prm->running_mean + c.c_off, prm->running_var + c.c_off,
+                                       prm->beta + c.c_off, prm->bias + c.c_off, prm->running_mean + c.c_off,
+                                       prm->running_var + c.c_off,
                                        prm->momentum, prm->eps, mean + c.c_off, rstd + c.c_off, scale + c.c_off,
                                        shift + c.c_off, st));
         TBN_TRY(tbn_launch_bn_apply(y, p.M, c.cout, scale + c.c_off, shift + c.c_off, zs, c.nparts, st));
@@ -589,7 +590,7 @@ int tbn_backbone_autotune(tbn_backbone_plan* P, int training, const tbn_backbone
         p.stride = c.stride;
         p.pad = c.pad;
         p.M = R * c.outH * c.outW;
-        p.bias = prm->bias + c.c_off;
+        p.bias = nullptr;
         if (c.stem) {
           p.wt = ws + P->wpack_off;
           p.Cin = P->kw;

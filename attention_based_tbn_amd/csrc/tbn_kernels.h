@@ -28,6 +28,7 @@ struct ConvP {
   double alg_flops;       // host only: algorithmic FLOPs of this launch (profiling)
   // ---- derived by tbn_launch_conv
   unsigned in_bytes, wt_bytes;          // buffer extents: out-of-range lanes read zeros (hardware check)
+  unsigned seg_bytes[3];                // extent of each output segment from seg[i].ptr
   int OHs, OWs;                         // output sub-grid this launch covers (m -> n, a, b)
   int out_sy, out_oy, out_sx, out_ox;   // full-grid output pixel = (a*out_sy+out_oy, b*out_sx+out_ox)
   int in_sy, in_sx;                     // input step per sub-grid step
@@ -75,8 +76,8 @@ int tbn_launch_weight_flip_transpose(const float* w, float* wt, int Cout, int ta
 int tbn_launch_bn_stats(const float* y, int ld, int P, int C, float* partial, int* nparts, hipStream_t st);
 int tbn_bn_stats_parts(int P, int C);
 int tbn_launch_bn_finalize(const float* partial, int nparts, int P, int C, const float* gamma, const float* beta,
-                           float* running_mean, float* running_var, float momentum, float eps, float* save_mean,
-                           float* save_rstd, float* scale, float* shift, hipStream_t st);
+                           const float* conv_bias, float* running_mean, float* running_var, float momentum, float eps,
+                           float* save_mean, float* save_rstd, float* scale, float* shift, hipStream_t st);
 int tbn_launch_bn_apply(const float* y, int P, int C, const float* scale, const float* shift, const Seg* segs,
                         int nseg, hipStream_t st);
 int tbn_launch_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var, const float* bias,

@@ -110,8 +110,10 @@ int tbn_backbone_backward(const tbn_backbone_plan* plan, const float* dfeatures,
 /* ---- single operators (same kernels the engine uses; used by the heads and the parity tests) ---- */
 
 /* nn.Conv2d forward, NHWC.  epilogue: 0 = +bias (optional ReLU / accumulate via flags: 1 accumulate
- * into out, 2 ReLU), 1 = +bias and per-channel (sum, sumsq) partials for training BN
- * (stat_partial[tbn_conv2d_stat_tiles()][2][cout]), 2 = +bias, *scale+shift, ReLU (eval BN).
+ * into out, 2 ReLU); 1 = bias-FREE conv output plus per-channel (sum, sumsq) partials for a following
+ * training-mode BN (stat_partial[tbn_conv2d_stat_tiles()][2][cout]) -- a per-channel constant cancels in
+ * batch-stat BN, so `bias` is ignored here and only enters the running mean (tbn_backbone_* does that);
+ * 2 = relu(conv * scale + shift) for eval BN (`bias` ignored: fold it into shift = beta + (bias-mean)*scale).
  * replaces: each nn.Conv2d of bn_inception_audio.py:24-401 (cuDNN).  cin must be a multiple of 32. */
 int tbn_conv2d_fwd(const float* in, int in_ld, const float* weight, const float* bias, float* out, int out_ld,
                    int n, int h, int w, int cin, int cout, int ksize, int stride, int pad, int epilogue, int flags,
