@@ -66,12 +66,12 @@ __device__ __forceinline__ float4 buf_load4(i32x4 r, unsigned voff, unsigned sof
 
 // EPI: 0 plain (+bias, optional ReLU / accumulate), 1 training-BN statistics, 2 eval-BN fold + ReLU,
 //      3 plain with output scatter (parity phase of a strided data gradient)
-template <int MT, int NT, bool ROWMODE, int EPI>
+template <int MT, int NT, bool ROWMODE, int EPI, int STAGES>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
   constexpr int BM = 128 * MT, BN = 32 * NT;
   constexpr int AR = 4 * MT;  // A rows per thread
   constexpr int TILE_F = (BM + BN) * LDT;  // floats per LDS stage (A rows then B rows)
-  __shared__ __attribute__((aligned(16))) float lds[2 * TILE_F];
+  __shared__ __attribute__((aligned(16))) float lds[STAGES * TILE_F];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // XCD-aware bijective remap: blocks b, b+8, ... share an XCD -> give them consecutive tiles
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
   for (int ks = 0; ks < ksteps; ++ks) {
     const bool more = (ks + 1 < ksteps) && !(p.flags & 4);   // flag 4: ablation, no loads in the loop
     if (more) load_tiles();  // global loads stay in flight under the MFMA phase
-    const float* As = lds + (ks & 1) * TILE_F;
+    const float* As = lds + (STAGES == 2 ? (ks & 1) * TILE_F : 0);
     const float* Bs = As + BM * LDT;
     float4 fa[2][MT], fb[2][NT];
     auto frag_load = [&](int buf, int kg) {
@@ -245,8 +245,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
         }
       }
     }
-    if (more) store_tiles(lds + ((ks + 1) & 1) * TILE_F);
-    if (!(p.flags & 64)) __syncthreads();   // flag 64: ablation, no barrier
+    if (STAGES == 2) {
+      if (more) store_tiles(lds + ((ks + 1) & 1) * TILE_F);
+      if (!(p.flags & 64)) __syncthreads();   // flag 64: ablation, no barrier
+    } else {  // single stage: everyone must be done reading before the tile is overwritten
+      __syncthreads();
+      if (more) {
+        store_tiles(lds);
+        __syncthreads();
+      }
+    }
   }
 
   // ---------------------------------------------------------------- epilogue
@@ -524,7 +532,10 @@ __global__ void weight_flip_transpose_kernel(const float* __restrict__ w, float*
 // ------------------------------------------------------------------------------------------ host
 template <int MT, int NT, bool RM, int EPI>
 static void launch_conv_e(const ConvP& p, hipStream_t st) {
-  hipLaunchKernelGGL((conv_igemm_kernel<MT, NT, RM, EPI>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, st, p);
+  if (p.stages == 2)
+    hipLaunchKernelGGL((conv_igemm_kernel<MT, NT, RM, EPI, 2>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, st, p);
+  else
+    hipLaunchKernelGGL((conv_igemm_kernel<MT, NT, RM, EPI, 1>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, st, p);
 }
 template <int MT, int NT, bool RM>
 static void launch_conv(const ConvP& p, hipStream_t st) {
@@ -565,12 +576,13 @@ void tbn_conv_pick_tile(int M, int Cout, int K, int* mt_out, int* nt_out) {
 
 static int launch_conv_tiles(ConvP& p, int rowmode, int mt, int nt, hipStream_t st) {
   if (mt <= 0 || nt <= 0) tbn_conv_pick_tile(p.M, p.Cout, p.K, &mt, &nt);
+  if (p.stages != 1 && p.stages != 2) p.stages = (mt == 1) ? 2 : 1;  // big tiles: keep 2 workgroups per CU
   p.tiles_m = cdiv(p.M, 128 * mt);
   p.tiles_n = cdiv(p.Cout, 32 * nt);
   {
     char nm[64];
     const int epi = p.mode == CONV_EPI_STATS ? 1 : (p.mode == CONV_EPI_EVAL ? 2 : ((p.out_sy != 1 || p.out_sx != 1) ? 3 : 0));
-    snprintf(nm, sizeof(nm), "conv_igemm_kernel<%d, %d, %s, %d>", mt, nt, rowmode ? "true" : "false", epi);
+    snprintf(nm, sizeof(nm), "conv_igemm_kernel<%d, %d, %s, %d, %d>", mt, nt, rowmode ? "true" : "false", epi, p.stages);
     tbn_prof_begin(nm, p.alg_flops, st);
   }
 #define TBN_CASE(MTv, NTv)                                     \

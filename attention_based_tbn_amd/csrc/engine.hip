@@ -52,8 +52,8 @@ struct Conv {
   int dst_buf[3], dst_choff[3];
   size_t w_off, c_off;
   size_t y_off;
-  int mt, nt;          // forward tile
-  int d_mt, d_nt;      // dgrad tile
+  int mt, nt, stages = 0;       // forward tile / LDS stages (0 = default)
+  int d_mt, d_nt, d_stages = 0; // dgrad tile
   bool stem;
   bool dgrad_accum;    // dgrad adds into d(inbuf)
   bool need_dgrad;
@@ -520,6 +520,7 @@ int tbn_backbone_forward(const tbn_backbone_plan* P, int training, const float* 
         p.seg[0].ld = c.cout;
         p.seg[0].col_begin = 0;
         p.stat_partial = ws + P->partial_off;
+        p.stages = c.stages;
         TBN_TRY(tbn_launch_conv(p, c.stem, c.mt, c.nt, st));
         TBN_TRY(tbn_launch_bn_finalize(ws + P->partial_off, cdiv(p.M, 128 * c.mt), p.M, c.cout, prm->gamma + c.c_off,
                                        prm->beta + c.c_off, prm->bias + c.c_off, prm->running_mean + c.c_off,
@@ -533,6 +534,7 @@ int tbn_backbone_forward(const tbn_backbone_plan* P, int training, const float* 
         p.shift = shift + c.c_off;
         p.nseg = c.nparts;
         for (int i = 0; i < c.nparts; ++i) p.seg[i] = zs[i];
+        p.stages = c.stages;
         TBN_TRY(tbn_launch_conv(p, c.stem, c.mt, c.nt, st));
       }
     } else {
@@ -639,30 +641,35 @@ int tbn_backbone_autotune(tbn_backbone_plan* P, int training, const tbn_backbone
         p.seg[0].ld = ib.C;
       }
       float best = 1e30f;
-      int bm = 1, bn = 1;
+      int bm = 1, bn = 1, bs = 2;
       for (int mt = 1; mt <= 2 && rc == TBN_OK; ++mt)
-        for (int nt = 1; nt <= 4 && rc == TBN_OK; ++nt) {
-          if (32 * (nt - 1) >= p.Cout) continue;
-          float ms = 0.f;
-          for (int rep = 0; rep < 2 && rc == TBN_OK; ++rep) {
-            hipEventRecord(e0, st);
-            rc = tbn_launch_conv(p, c.stem && pass == 0, mt, nt, st);
-            hipEventRecord(e1, st);
-            hipEventSynchronize(e1);
-            hipEventElapsedTime(&ms, e0, e1);
+        for (int nt = 1; nt <= 4 && rc == TBN_OK; ++nt)
+          for (int stg = 1; stg <= 2 && rc == TBN_OK; ++stg) {
+            if (32 * (nt - 1) >= p.Cout) continue;
+            float ms = 0.f;
+            p.stages = stg;
+            for (int rep = 0; rep < 2 && rc == TBN_OK; ++rep) {
+              (void)hipEventRecord(e0, st);
+              rc = tbn_launch_conv(p, c.stem && pass == 0, mt, nt, st);
+              (void)hipEventRecord(e1, st);
+              (void)hipEventSynchronize(e1);
+              (void)hipEventElapsedTime(&ms, e0, e1);
+            }
+            if (ms < best) {
+              best = ms;
+              bm = mt;
+              bn = nt;
+              bs = stg;
+            }
           }
-          if (ms < best) {
-            best = ms;
-            bm = mt;
-            bn = nt;
-          }
-        }
       if (pass == 0) {
         c.mt = bm;
         c.nt = bn;
+        c.stages = bs;
       } else {
         c.d_mt = bm;
         c.d_nt = bn;
+        c.d_stages = bs;
       }
     }
     if (rc != TBN_OK) break;
@@ -814,6 +821,7 @@ int tbn_backbone_backward(const tbn_backbone_plan* P, const float* dfeatures, co
       p.seg[0].ptr = ws + ib.doff;
       p.seg[0].ld = ib.C;
       p.seg[0].col_begin = 0;
+      p.stages = c.d_stages;
       TBN_TRY(tbn_launch_conv(p, 0, c.d_mt, c.d_nt, st));
     }
   }

@@ -26,6 +26,7 @@ struct ConvP {
   int tiles_m, tiles_n;
   int mode, flags;
   double alg_flops;       // host only: algorithmic FLOPs of this launch (profiling)
+  int stages;             // host only: LDS stages (1 = two barriers per K-step, 2 = double buffered); 0 = default
   // ---- derived by tbn_launch_conv
   unsigned in_bytes, wt_bytes;          // buffer extents: out-of-range lanes read zeros (hardware check)
   unsigned seg_bytes[3];                // extent of each output segment from seg[i].ptr
