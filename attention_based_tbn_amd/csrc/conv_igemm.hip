@@ -391,58 +391,58 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  constexpr int AF = KR * 8 * MT, BF = KR * 8 * NT;  // float4 items per tile
-  constexpr int AI = (AF + 63) / 64, BI = (BF + 63) / 64;
+  // VALU diet (the fp32 MFMA shares the VALU lanes: every VALU op costs MFMA time).  Lane l owns ONE pixel
+  // row of the 16-row step (row = l >> 2) and the float4 columns {q, q+4, q+8, ...} (q = l & 3): the row is
+  // decoded once per lane per step and the column stride rides in the load's immediate offset; 4 lanes x 16 B
+  // still make 64-B contiguous requests per row.
+  constexpr int AI = 2 * MT, BI = 2 * NT;
   float4 ra[AI], rb[BI];
-
+  const int lrow16 = lane >> 2, lq = lane & 3;
+  const bool a_full = (co0 + 32 * MT <= p.Cout), b_full = (ci0 + 32 * NT <= p.Cin);
   const i32x4 dy_rsrc = make_rsrc(p.dy, p.dy_bytes);
   const i32x4 x_rsrc = make_rsrc(p.x, p.x_bytes);
   auto load_tiles = [&](int row0) {
+    const int m = row0 + lrow16;
+    const bool row_ok = m < pend;
+    {
+      const unsigned base = row_ok ? ((unsigned)m * (unsigned)p.dy_ld + (unsigned)(co0 + lq * 4)) * 4u : TBN_OOB;
 #pragma unroll
-    for (int i = 0; i < AI; ++i) {
-      const int f = lane + 64 * i;
-      const int row = f / (8 * MT), c = (f - row * (8 * MT)) * 4;
-      const int m = row0 + row;
-      const bool ok = (f < AF) && (m < pend) && (co0 + c < p.Cout);
-      ra[i] = buf_load4(dy_rsrc, ok ? ((unsigned)m * (unsigned)p.dy_ld + (unsigned)(co0 + c)) * 4u : TBN_OOB);
-    }
-#pragma unroll
-    for (int i = 0; i < BI; ++i) {
-      const int f = lane + 64 * i;
-      const int row = f / (8 * NT), c = (f - row * (8 * NT)) * 4;
-      const int m = row0 + row;
-      const uint32_t n = fdiv((uint32_t)m, p.div_ohw);
-      const uint32_t rem = (uint32_t)m - n * p.div_ohw.d;
-      const uint32_t oy = fdiv(rem, p.div_ow);
-      const uint32_t ox = rem - oy * p.div_ow.d;
-      const int iy = (int)oy * p.stride - p.pad + r;
-      const int ix = (int)ox * p.stride - p.pad + s;
-      const int cc = ci0 + c;
-      bool ok = (f < BF) && (m < pend) && (cc < p.Cin) && ((unsigned)iy < (unsigned)p.H);
-      unsigned off;
-      if (!ROWMODE) {
-        ok = ok && ((unsigned)ix < (unsigned)p.W);
-        off = (((n * p.H + iy) * p.W + ix) * (unsigned)p.x_ld + (unsigned)cc) * 4u;
-      } else {
-        ok = ok && ((unsigned)(ix + cc / p.cp) < (unsigned)p.W);
-        off = (unsigned)((int)(((n * p.H + iy) * p.W) * (unsigned)p.cp) + ix * p.cp + cc) * 4u;
+      for (int k = 0; k < AI; ++k) {
+        const bool ok = a_full || (co0 + lq * 4 + 16 * k < p.Cout);
+        ra[k] = buf_load4(dy_rsrc, ok ? base + 64u * k : TBN_OOB);
       }
-      rb[i] = buf_load4(x_rsrc, ok ? off : TBN_OOB);
+    }
+    const uint32_t n = fdiv((uint32_t)m, p.div_ohw);
+    const uint32_t rem = (uint32_t)m - n * p.div_ohw.d;
+    const uint32_t oy = fdiv(rem, p.div_ow);
+    const uint32_t ox = rem - oy * p.div_ow.d;
+    const int iy = (int)oy * p.stride - p.pad + r;
+    const int ix = (int)ox * p.stride - p.pad + s;
+    if (!ROWMODE) {
+      const bool okrow = row_ok && ((unsigned)iy < (unsigned)p.H) && ((unsigned)ix < (unsigned)p.W);
+      const unsigned base =
+          okrow ? (((n * p.H + iy) * p.W + ix) * (unsigned)p.x_ld + (unsigned)(ci0 + lq * 4)) * 4u : TBN_OOB;
+#pragma unroll
+      for (int k = 0; k < BI; ++k) {
+        const bool ok = b_full || (ci0 + lq * 4 + 16 * k < p.Cin);
+        rb[k] = buf_load4(x_rsrc, ok ? base + 64u * k : TBN_OOB);
+      }
+    } else {
+      const bool okrow = row_ok && ((unsigned)iy < (unsigned)p.H);
+#pragma unroll
+      for (int k = 0; k < BI; ++k) {
+        const int cc = ci0 + lq * 4 + 16 * k;
+        const bool ok = okrow && (cc < p.Cin) && ((unsigned)(ix + cc / p.cp) < (unsigned)p.W);
+        const unsigned off = (unsigned)((int)(((n * p.H + iy) * p.W) * (unsigned)p.cp) + ix * p.cp + cc) * 4u;
+        rb[k] = buf_load4(x_rsrc, ok ? off : TBN_OOB);
+      }
     }
   };
   auto store_tiles = [&]() {
 #pragma unroll
-    for (int i = 0; i < AI; ++i) {
-      const int f = lane + 64 * i;
-      const int row = f / (8 * MT), c = (f - row * (8 * MT)) * 4;
-      if (f < AF) *reinterpret_cast<float4*>(&At[row * WA + c]) = ra[i];
-    }
+    for (int k = 0; k < AI; ++k) *reinterpret_cast<float4*>(&At[lrow16 * WA + lq * 4 + 16 * k]) = ra[k];
 #pragma unroll
-    for (int i = 0; i < BI; ++i) {
-      const int f = lane + 64 * i;
-      const int row = f / (8 * NT), c = (f - row * (8 * NT)) * 4;
-      if (f < BF) *reinterpret_cast<float4*>(&Bt[row * WB + c]) = rb[i];
-    }
+    for (int k = 0; k < BI; ++k) *reinterpret_cast<float4*>(&Bt[lrow16 * WB + lq * 4 + 16 * k]) = rb[k];
   };
 
   // every wave runs the same trip count (rows beyond pend load zeros) so barriers line up
