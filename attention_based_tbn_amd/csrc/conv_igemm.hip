@@ -445,13 +445,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
     for (int k = 0; k < BI; ++k) *reinterpret_cast<float4*>(&Bt[lrow16 * WB + lq * 4 + 16 * k]) = rb[k];
   };
 
-  // every wave runs the same trip count (rows beyond pend load zeros) so barriers line up
+  // The LDS tiles are wave-private and a wave's LDS operations execute in program order, so the main loop
+  // needs NO workgroup barrier: the four waves run decoupled (wave_barrier only pins the compiler's order).
   const int nsteps = (p.rows_per_split + 4 * KR - 1) / (4 * KR);
   const int lrow = lane & 31, lhalf = lane >> 5;
   load_tiles(pbeg + wave * KR);
   for (int it = 0; it < nsteps; ++it) {
     store_tiles();
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();
     if (it + 1 < nsteps) load_tiles(pbeg + ((it + 1) * 4 + wave) * KR);
 #pragma unroll
     for (int kp = 0; kp < KR / 2; ++kp) {
@@ -466,8 +467,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
         for (int j = 0; j < NT; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bb[j], acc[i][j], 0, 0, 0);
     }
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();
   }
+  __syncthreads();  // the reduction buffer below overlays every wave's tiles
 
   // cross-wave reduction, one 32x32 sub-tile at a time: red[wave][32*32]
   float* red = lds;
