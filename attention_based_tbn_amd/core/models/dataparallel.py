@@ -5,8 +5,8 @@ parameter broadcast + scatter/gather + reduce to GPU 0).  Here every rank holds 
 the full forward/backward on its own shard of the clips (per-replica BatchNorm statistics, as
 nn.DataParallel's chunks had) and gradients are averaged with ONE collective per parameter
 tensor -- the backbones keep their parameters in a few flat tensors, so that is a handful of
-large all-reduces (~41 MB per backbone) launched as soon as each backbone's backward finishes and
-overlapped with the rest of the backward on RCCL's stream.  No collective on the data path.
+large all-reduces (~41 MB per backbone), issued on RCCL's stream at the end of backward (when the
+engine has joined the per-backbone side streams).  No collective on the data path.
 
 `DataParallel(model)` keeps the reference surface: `.module`, `forward`, `get_loss(...)`,
 `state_dict()` of the wrapped model under the `module.` prefix.
@@ -23,6 +23,7 @@ class DataParallel(nn.Module):
         self.device_ids = device_ids
         self.process_group = process_group
         self._pending = []
+        self._ready = []
         self._callback_queued = False
         self._hooks = []
         self.world_size = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
@@ -40,23 +41,33 @@ class DataParallel(nn.Module):
                 dist.broadcast(t, src, group=self.process_group)
 
     def _on_grad_ready(self, p):
-        g = p.grad
-        if dist.get_backend(self.process_group) == "nccl":
-            work = dist.all_reduce(g, op=dist.ReduceOp.AVG, group=self.process_group, async_op=True)
-            self._pending.append((work, None))
-        else:
-            work = dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.process_group, async_op=True)
-            self._pending.append((work, g))
+        """post-accumulate-grad hook: remember the tensor, arrange ONE callback at the end of backward.
+
+        The collectives are issued from that callback, not from here: the backbones run their backward
+        on side HIP streams, and the autograd engine only guarantees that the caller's current stream
+        has waited for every leaf stream once backward is complete (it syncs them right before the
+        final callbacks run).  Issuing there is correct by construction; the all-reduces of the few flat
+        tensors (3 x ~41 MB + heads) then run back to back on RCCL's stream."""
+        self._ready.append(p)
         if not self._callback_queued:
             self._callback_queued = True
             torch.autograd.Variable._execution_engine.queue_callback(self.finish_gradient_sync)
 
     def finish_gradient_sync(self):
-        """wait for the in-flight all-reduces (stream-level on RCCL); runs at the end of backward"""
-        for work, g in self._pending:
-            work.wait()
+        """average every gradient produced by this backward across ranks (RCCL all-reduce)"""
+        avg = dist.get_backend(self.process_group) == "nccl"
+        works = []
+        for p in self._ready:
+            g = p.grad
+            if g is None:
+                continue
+            op = dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM
+            works.append((dist.all_reduce(g, op=op, group=self.process_group, async_op=True), None if avg else g))
+        for work, g in works:
+            work.wait()          # stream-level wait on RCCL; host-blocking only on gloo
             if g is not None:
                 g.div_(self.world_size)
+        self._ready = []
         self._pending = []
         self._callback_queued = False
 

@@ -1,0 +1,72 @@
+"""GPU: the real TBN model under the data-parallel wrapper with 2 ranks (both on cuda:0, gloo backend --
+RCCL needs one GPU per rank, which a 1-GPU box cannot give): every rank's averaged gradient must equal the
+mean of the two ranks' local gradients, and replicas must start identical after the wrap-time broadcast."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+_WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from attention_based_tbn_amd.config import load_config, get_modality
+from attention_based_tbn_amd.core.models import build_model, DataParallel
+dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=2)
+rank = dist.get_rank()
+dev = torch.device("cuda:0")
+cfg = load_config(["data.flow.enable=False", "data.audio.audio_length=1.279", "model.fusion_dropout=0",
+                   "model.attention.attn_dropout=0.0"])
+modality = get_modality(cfg)
+torch.manual_seed(10 + rank)                              # replicas differ until the broadcast
+model, crit, _ = build_model(cfg, modality, dev)
+assert isinstance(model, DataParallel) and model.world_size == 2
+sd = model.module.state_dict()
+ref = [torch.empty_like(sd["classifier.verb.weight"]) for _ in range(2)]
+dist.all_gather(ref, sd["classifier.verb.weight"])
+assert torch.equal(ref[0], ref[1])                       # broadcast made the replicas identical
+g = torch.Generator().manual_seed(100 + rank)            # each rank its own shard of clips
+B, n = 2, 3
+inp = {"RGB": (torch.rand(B, n, 3, 64, 64, generator=g) - 0.45).to(dev),
+       "Audio": (torch.randn(B, n, 1, 128, 256, generator=g) * 3 - 6).to(dev)}
+tgt = {"class": {"verb": torch.randint(0, 125, (B,), generator=g).to(dev), "noun": torch.randint(0, 352, (B,), generator=g).to(dev)}}
+model.train()
+def run(m):
+    for p in m.parameters(): p.grad = None
+    st = {k: v.clone() for k, v in model.module.state_dict().items()}
+    out = m(inp); loss, _ = m.get_loss(crit, tgt, out, 12); loss["total"].backward()
+    torch.cuda.synchronize()
+    model.module.load_state_dict(st)                      # undo the BN running-stat update
+    return {k: p.grad.clone() for k, p in model.module.named_parameters() if p.grad is not None}
+local = run(model.module)                                 # no collective
+synced = run(model)                                       # hooks + all-reduce at the end of backward
+for k, gl in local.items():
+    parts = [torch.empty_like(gl) for _ in range(2)]
+    dist.all_gather(parts, gl)
+    want = (parts[0] + parts[1]) / 2
+    err = float((synced[k] - want).abs().max() / (want.abs().max() + 1e-20))
+    assert err < 1e-5, (k, err)
+assert len(local) >= 12 and model._ready == []
+print("DP_GPU_OK", rank, len(local))
+'''
+
+
+def test_dataparallel_real_model_two_ranks_on_one_gpu(tmp_path):
+    script = tmp_path / "dp_gpu_worker.py"
+    script.write_text(_WORKER)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   OMP_NUM_THREADS="2")
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"DP_GPU_OK {r}" in o, o[-3000:]
