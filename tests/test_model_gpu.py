@@ -272,3 +272,33 @@ def test_state_dict_roundtrip_with_oracle_checkpoint():
     back = model.state_dict()
     for k, v in oracle.state_dict().items():
         assert torch.equal(back[k].cpu(), v), k
+
+
+def test_eval_chunking_config5_shape():
+    """config-5 style eval (25 segments): more frames than one engine call takes (eval_chunk) must give
+    the same logits as a single call, and the MHA weights keep the reference shape (B*n, 1, T)"""
+    from attention_based_tbn_amd.config import load_config, get_modality
+    from attention_based_tbn_amd.core.models import build_model
+    cfg = load_config(["data.audio.audio_length=1.279", "data.flow.enable=False"])
+    modality = get_modality(cfg)
+    torch.manual_seed(1)
+    model, crit, _ = build_model(cfg, modality, DEV)
+    with torch.no_grad():
+        for m in modality:
+            b = getattr(model, "Base_" + m)
+            b.running_var.uniform_(0.5, 1.5)
+            b.running_mean.normal_(0, 0.1)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    B, n = 3, 25                                  # 75 frames per modality
+    inp = {"RGB": torch.rand(B, n, 3, 224, 224, device=DEV, generator=g) - 0.45,
+           "Audio": torch.randn(B, n, 1, 256, 256, device=DEV, generator=g) * 3 - 6}
+    model.eval()
+    with torch.no_grad():
+        one = model(inp)
+        for m in modality:
+            getattr(model, "Base_" + m).eval_chunk = 32     # 75 frames -> 32 + 32 + 11
+        chunked = model(inp)
+    assert one["weights"].shape == (B * n, 1, 8)
+    assert abs(float(one["weights"].sum(-1).mean()) - 1.0) < 1e-5
+    for k in ("verb", "noun", "weights"):
+        assert rel_err(chunked[k].cpu(), one[k].cpu()) < 1e-5, k
