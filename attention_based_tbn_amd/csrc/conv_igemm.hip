@@ -303,10 +303,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
         unsigned voff = vbase, soff = (unsigned)(dm * old) * 4u;
         if (scatter) {
           const int m = mrow0 + i * 32 + dm;
-          const int ohw = p.OHs * p.OWs;
-          const int n = m / ohw, rem = m - n * ohw;
-          const int a = rem / p.OWs, b = rem - a * p.OWs;
-          const unsigned opix = (unsigned)((n * p.OH + (a * p.out_sy + p.out_oy)) * p.OW + (b * p.out_sx + p.out_ox));
+          const uint32_t n = fdiv((uint32_t)m, p.div_ohw);
+          const uint32_t rem = (uint32_t)m - n * p.div_ohw.d;
+          const uint32_t a = fdiv(rem, p.div_ow);
+          const uint32_t b = rem - a * p.div_ow.d;
+          const unsigned opix = (unsigned)(((int)n * p.OH + ((int)a * p.out_sy + p.out_oy)) * p.OW + ((int)b * p.out_sx + p.out_ox));
           voff = (m < p.M && col_ok) ? opix * (unsigned)old * 4u + col_off : TBN_OOB;
           soff = 0u;
         } else if (!tile_full) {
