@@ -364,8 +364,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
   float* At = lds + wave * TILE;
   float* Bt = At + KR * WA;
 
-  // block -> (split, tap, tile_ci, tile_co); co fastest so neighbours share the x rows in L2
-  int b = blockIdx.x;
+  // block -> (split, tap, tile_ci, tile_co), split slowest.  All tiles x taps of one split re-read the same
+  // dy / x row slab, so the XCD-aware bijective remap (blocks b, b+8, ... share an XCD and its L2) hands each
+  // XCD a CONTIGUOUS run of logical ids: a slab is then fetched into one L2 instead of all eight.
+  int b;
+  {
+    const int nb = gridDim.x, bid = blockIdx.x;
+    const int q8 = nb >> 3, r8 = nb & 7, xcd = bid & 7, idx = bid >> 3;
+    b = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+  }
   const int tco = b % p.tiles_co;
   b /= p.tiles_co;
   const int tci = b % p.tiles_ci;

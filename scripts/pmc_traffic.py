@@ -1,0 +1,59 @@
+#!/usr/bin/env python
+"""Summarise the two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs, see
+MI355X_MICROARCH.md HBM section) of `bench.py --profile-every 1` into HBM bytes per launch per
+kernel.  FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 128-B requests as 64 B for
+wide coalesced reads, so the read side is doubled (upper bound for narrow reads).
+
+  python scripts/pmc_traffic.py gpurun_out/pmc_fetch/fetch_counter_collection.csv \
+         gpurun_out/pmc_write/write_counter_collection.csv profiles/r01_pmc_traffic.json
+"""
+import csv
+import json
+import re
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    name = re.sub(r"^void ", "", name)
+    name = re.sub(r"\(.*$", "", name)
+    return name.replace("(anonymous namespace)::", "")
+
+
+def load(path, counter):
+    acc = defaultdict(lambda: [0, 0.0])
+    with open(path) as f:
+        for row in csv.DictReader(f):
+            if row["Counter_Name"] != counter:
+                continue
+            k = short(row["Kernel_Name"])
+            acc[k][0] += 1
+            acc[k][1] += float(row["Counter_Value"])
+    return acc
+
+
+def main():
+    fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
+    out = {}
+    for k in sorted(set(fetch) | set(write)):
+        nf, f = fetch.get(k, [0, 0.0])
+        nw, w = write.get(k, [0, 0.0])
+        if not nf or not nw:
+            continue
+        rd = 2.0 * 1024.0 * f / nf
+        wr = 1024.0 * w / nw
+        out[k] = {"launches": nf, "fetch_kib_raw_per_launch": round(f / nf, 2), "write_kib_per_launch": round(w / nw, 2),
+                  "hbm_read_bytes_per_launch": round(rd), "hbm_write_bytes_per_launch": round(wr),
+                  "hbm_bytes_per_launch": round(rd + wr)}
+    tot = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in out.values())
+    res = {"note": "FETCH_SIZE x2 gfx950 correction applied to reads; separate --pmc passes; bytes per launch averaged over "
+                   "all launches of that kernel name in bench.py --steps 3 --warmup 2 --profile-every 1 (B=32)",
+           "total_hbm_bytes_all_launches": tot, "kernels": out}
+    with open(sys.argv[3], "w") as f:
+        json.dump(res, f, indent=1)
+    for k, v in sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"])[:14]:
+        print(f"{k[:70]:70s} n={v['launches']:5d} rd={v['hbm_read_bytes_per_launch']/1e6:9.2f} MB wr={v['hbm_write_bytes_per_launch']/1e6:9.2f} MB")
+
+
+if __name__ == "__main__":
+    main()
