@@ -21,11 +21,21 @@
 // ROWMODE is the 7x7 stem: input is NHWC padded to `cp` channels, a filter row (7*cp floats,
 //   padded to a multiple of 32) is one contiguous K run.
 #include <cstdio>
+#include <type_traits>
 
 #include "tbn_common.h"
 #include "tbn_kernels.h"
 
+#ifndef TBN_WPAD
+#define TBN_WPAD 4
+#endif
 #define LDT 36  // LDS row pitch in floats (32 + 4): 16-B aligned rows, conflict-free b128 reads
+// Timing ablations of the main loop (scripts/conv_ablate.py) exist only in a -DTBN_ABLATE=1 build: as run-time
+// flags their scalar branches cut the K loop into basic blocks and cost the production kernel ~10 %.
+#ifndef TBN_ABLATE
+#define TBN_ABLATE 0
+#endif
+#define ABL(bit) (TBN_ABLATE && (p.flags & (bit)))
 
 // Hardware-bounds-checked 16-B loads.  ROCm 7.2's clang lowers __builtin_amdgcn_raw_buffer_load_b128 to a
 // ONE-dword load, so the LLVM intrinsic is bound directly (same idiom as composable_kernel).
@@ -129,7 +139,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
     }
   }
 
-  if (p.flags & 128) {  // ablation: exit after the per-row setup
+  if (ABL(128)) {  // ablation: exit after the per-row setup
     if (a_off[0] == 0x12345u && a_mask[AR - 1] == 77u) p.seg[0].ptr[0] = (float)a_ix[0];
     return;
   }
@@ -201,18 +211,19 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
   load_tiles();
   store_tiles(lds);
   __syncthreads();
-  if (p.flags & 256) {  // ablation: exit after the prologue tile
+  if (ABL(256)) {  // ablation: exit after the prologue tile
     if (lds[tid] == 12345.678f) p.seg[0].ptr[0] = 1.f;
     return;
   }
 
   const int lrow = lane & 31, lhalf = lane >> 5;
-  int nt_act = (p.Cout - n0 + 31) >> 5;  // active 32-column sub-tiles of this block (block-uniform)
-  if (nt_act > NT) nt_act = NT;
   // two LDS stages, ONE barrier per K-step: the stage written in step ks was last read in step ks-1,
-  // and every wave has passed the barrier that ended step ks-1 before any wave writes it
+  // and every wave has passed the barrier that ended step ks-1 before any wave writes it.
+  // The fragment reads and MFMAs of a K-step are ONE basic block (no run-time conditions inside), so the
+  // scheduler issues the ds_reads ahead of the MFMAs that hide them.  A ragged last N tile multiplies its
+  // zero-filled weight rows (rows >= Cout are out-of-range loads) instead of branching around MFMAs.
   for (int ks = 0; ks < ksteps; ++ks) {
-    const bool more = (ks + 1 < ksteps) && !(p.flags & 4);   // flag 4: ablation, no loads in the loop
+    const bool more = (ks + 1 < ksteps) && !ABL(4);   // flag 4: ablation, no loads in the loop
     if (more) load_tiles();  // global loads stay in flight under the MFMA phase
     const float* As = lds + (STAGES == 2 ? (ks & 1) * TILE_F : 0);
     const float* Bs = As + BM * LDT;
@@ -226,28 +237,44 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
       for (int j = 0; j < NT; ++j)
         fb[buf][j] = *reinterpret_cast<const float4*>(&Bs[(j * 32 + lrow) * LDT + kg * 8 + lhalf * 4]);
     };
-    if (!(p.flags & 32)) frag_load(0, 0);   // flag 32: ablation, no LDS fragment reads
+    auto mfma_group = [&](int buf) {
+      // the 4 MFMAs of one accumulator stay back to back: a dependent MFMA is only free when it directly
+      // follows its producer (scripts/ubench: alternating two accumulators halves the rate)
 #pragma unroll
-    for (int kg = 0; kg < 4; ++kg) {
-      if (kg < 3 && !(p.flags & 32)) frag_load((kg + 1) & 1, kg + 1);
-      const float4* a = fa[kg & 1];
-      const float4* b = fb[kg & 1];
+      for (int j = 0; j < NT; ++j)
 #pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        if (j < nt_act && !(p.flags & 8)) {   // flag 8: ablation, no MFMA
-#pragma unroll
-          for (int i = 0; i < MT; ++i) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
-          }
+        for (int i = 0; i < MT; ++i) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[buf][i].x, fb[buf][j].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[buf][i].y, fb[buf][j].y, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[buf][i].z, fb[buf][j].z, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[buf][i].w, fb[buf][j].w, acc[i][j], 0, 0, 0);
         }
-      }
+    };
+    // software pipeline over the four 8-wide k groups: the fragments of group g+1 are read while group g
+    // multiplies; the sched_group_barrier chain pins that order (DS-read group, MFMA group, ...)
+    if (!ABL(32)) {   // flag 32: ablation, no LDS fragment reads
+      frag_load(0, 0);
+      frag_load(1, 1);
+    }
+    if (!ABL(8)) mfma_group(0);   // flag 8: ablation, no MFMA
+    if (!ABL(32)) frag_load(0, 2);
+    if (!ABL(8)) mfma_group(1);
+    if (!ABL(32)) frag_load(1, 3);
+    if (!ABL(8)) mfma_group(0);
+    if (!ABL(8)) mfma_group(1);
+    if (!TBN_ABLATE) {
+      constexpr int NR = MT + NT, NM = 4 * MT * NT;
+      __builtin_amdgcn_sched_group_barrier(0x100, 2 * NR, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, NR, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, NR, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 2 * NM, 0);
+      __builtin_amdgcn_sched_barrier(0);  // keep the barrier (and its lgkmcnt(0)) below the last MFMA group
     }
     if (STAGES == 2) {
       if (more) store_tiles(lds + ((ks + 1) & 1) * TILE_F);
-      if (!(p.flags & 64)) __syncthreads();   // flag 64: ablation, no barrier
+      if (!ABL(64)) __syncthreads();   // flag 64: ablation, no barrier
     } else {  // single stage: everyone must be done reading before the tile is overwritten
       __syncthreads();
       if (more) {
@@ -355,7 +382,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
 // in fixed order (deterministic), then stored to `out` (final dW or a split-K slab).
 template <int MT, int NT, bool ROWMODE>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
-  constexpr int WA = 32 * MT + 4, WB = 32 * NT + 4;  // LDS pitches
+  constexpr int WA = 32 * MT + TBN_WPAD, WB = 32 * NT + TBN_WPAD;  // LDS pitches
   constexpr int KR = 16;                             // pixel rows per wave step
   constexpr int TILE = KR * (WA + WB);
   constexpr int LDSF = (4 * TILE > 4 * 1024 ? 4 * TILE : 4 * 1024);

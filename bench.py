@@ -25,17 +25,34 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FLOP_PER_CLIP_FWD_BWD = 120.63e9      # BASELINE.md section 3 (convs only, 3 modalities x 3 segments)
+# BASELINE.json configs[1..4]: overrides, batch per GPU, segments, mode, conv GFLOP per clip
+CONFIGS = {
+    2: dict(name="BASELINE config 2: RGB-only, attention off, 3 segments, 224x224, train step",
+            ov=["data.flow.enable=False", "data.audio.enable=False", "model.attention.enable=False"],
+            batch=32, train=True, gflop=35.86),
+    3: dict(name="BASELINE config 3: RGB+Audio sync, MHA fusion + entropy loss, 3 segments, 1.279 s audio, train step",
+            ov=["data.flow.enable=False", "data.audio.audio_length=1.279", "model.attention.use_entropy=True"],
+            batch=64, train=True, gflop=81.47),
+    4: dict(name="BASELINE config 4: RGB+Flow+Audio async, attention off, 3 segments, 224x224 frames "
+                 "+ 1.279 s (256x256) spectrogram, train step fwd+loss+bwd+clip+SGD",
+            ov=["model.attention.enable=False", "data.audio.audio_length=1.279", "data.sampling=async"],
+            batch=32, train=True, gflop=120.63),
+    5: dict(name="BASELINE config 5: RGB+Flow+Audio sync, MHA fusion, 25 test segments, eval forward + consensus",
+            ov=["data.audio.audio_length=1.279"], batch=64, train=False, gflop=344.47),
+}
 PEAK_FP32_MFMA_TFLOPS = 157.3         # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 
 
-def synthetic_batch(B, n, device, seed):
+def synthetic_batch(B, n, device, seed, modality=("RGB", "Flow", "Audio")):
     g = torch.Generator(device=device).manual_seed(seed)
     mean = torch.tensor([0.408, 0.459, 0.502], device=device).view(1, 1, 3, 1, 1)
-    inp = {
-        "RGB": torch.rand(B, n, 3, 224, 224, device=device, generator=g) - mean,
-        "Flow": torch.rand(B, n, 10, 224, 224, device=device, generator=g) - 0.502,
-        "Audio": (torch.randn(B, n, 1, 256, 256, device=device, generator=g) * 3 - 6).clamp_(-13.8155, 8.0),
-    }
+    inp = {}
+    if "RGB" in modality:
+        inp["RGB"] = torch.rand(B, n, 3, 224, 224, device=device, generator=g) - mean
+    if "Flow" in modality:
+        inp["Flow"] = torch.rand(B, n, 10, 224, 224, device=device, generator=g) - 0.502
+    if "Audio" in modality:
+        inp["Audio"] = (torch.randn(B, n, 1, 256, 256, device=device, generator=g) * 3 - 6).clamp_(-13.8155, 8.0)
     tgt = {"class": {"verb": torch.randint(0, 125, (B,), device=device, generator=g),
                      "noun": torch.randint(0, 352, (B,), device=device, generator=g)}}
     return inp, tgt
@@ -94,7 +111,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch-per-gpu", type=int, default=32)
+    ap.add_argument("--config", type=int, default=4, choices=sorted(CONFIGS),
+                    help="BASELINE.json config (4 = the headline metric; 2, 3, 5 are the other single-GPU-sized configs)")
+    ap.add_argument("--batch-per-gpu", type=int, default=0, help="clips per GPU (default: the config's)")
+    ap.add_argument("--forward-only", action="store_true", help="time the forward pass only (training-mode BN)")
+    ap.add_argument("--no-multi-stream", action="store_true", help="diagnostic: run the modality backbones on one stream")
+    ap.add_argument("--no-aux-stream", action="store_true", help="diagnostic: weight gradients on the backbone's own stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-every", type=int, default=20, help="bracket conv-GEMM launches with HIP events on every k-th timed step")
     args = ap.parse_args()
@@ -113,20 +135,40 @@ def main():
     from attention_based_tbn_amd.config import load_config, get_modality
     from attention_based_tbn_amd.core.models import build_model
     from attention_based_tbn_amd._lib import lib
-    cfg = load_config(["model.attention.enable=False", "data.audio.audio_length=1.279", "data.sampling=async"])
+    C_ = CONFIGS[args.config]
+    cfg = load_config(C_["ov"])
     modality = get_modality(cfg)
     torch.manual_seed(0)
     model, criterion, _ = build_model(cfg, modality, device)
-    model.train()
+    model.train(C_["train"])
     core = getattr(model, "module", model)
     bases = [getattr(core, "Base_" + m) for m in modality]
     params = [p for p in model.parameters() if p.requires_grad]
     opt = torch.optim.SGD(params, lr=cfg.train.optim.lr, momentum=cfg.train.optim.momentum,
                           weight_decay=cfg.train.optim.weight_decay)
-    B, n = args.batch_per_gpu, cfg.train.num_segments
-    inp, tgt = synthetic_batch(B, n, device, seed=rank)   # clips are sharded by rank: no data-path collective
+    B = args.batch_per_gpu or C_["batch"]
+    n = cfg.train.num_segments if C_["train"] else cfg.test.num_segments
+    inp, tgt = synthetic_batch(B, n, device, seed=rank, modality=modality)   # clips are sharded by rank: no data-path collective
+    flop_per_clip = C_["gflop"] * 1e9
+    if C_["train"] and args.forward_only:
+        flop_per_clip = {2: 12.190, 3: 27.494, 4: 41.336}[args.config] * 1e9
+
+    def eval_step():
+        with torch.no_grad():
+            out = model(inp)
+        return out["verb"].float().sum() * 0 + 1.0
+
+    def fwd_step():
+        with torch.no_grad():
+            out = model(inp)
+            loss, _ = model.get_loss(criterion, tgt, out, 0)
+        return loss["total"]
 
     def step():
+        if not C_["train"]:
+            return eval_step()
+        if args.forward_only:
+            return fwd_step()
         opt.zero_grad(set_to_none=True)
         out = model(inp)
         loss, _ = model.get_loss(criterion, tgt, out, 0)
@@ -134,6 +176,11 @@ def main():
         torch.nn.utils.clip_grad_norm_(params, cfg.train.clip_grad)
         opt.step()
         return loss["total"]
+
+    multi, aux = not args.no_multi_stream, not args.no_aux_stream
+    core.multi_stream = multi
+    for b_ in bases:
+        b_.use_aux_stream = aux
 
     def fence():
         torch.cuda.synchronize()
@@ -159,9 +206,9 @@ def main():
         loss = step()
         if prof:
             L.tbn_profile_enable(0)
-            core.multi_stream = True
+            core.multi_stream = multi
             for b_ in bases:
-                b_.use_aux_stream = True
+                b_.use_aux_stream = aux
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -187,21 +234,22 @@ def main():
                         "all_conv_gemm": {"achieved": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2),
                                           "frac": round(tot_fl / (tot_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
                                           "ms_per_profiled_step": round(tot_ms / max(1, len(range(0, args.steps, args.profile_every))), 2)},
-                        "end_to_end_frac": round(value / world * FLOP_PER_CLIP_FWD_BWD / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                        "end_to_end_frac": round(value / world * flop_per_clip / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
                         "by_kernel": [{"kernel": e["kernel"], "launches": e["launches"],
                                        "avg_us": round(1e3 * e["ms"] / e["launches"], 2),
                                        "tflops": round(e["flops"] / (e["ms"] * 1e-3) / 1e12, 2)} for e in prof[:8]]}
         line = {
-            "metric": "clips/sec (3-seg RGB+Flow+Audio TBN fwd+bwd)", "value": round(value, 2), "unit": "clips/s",
+            "metric": "clips/sec (3-seg RGB+Flow+Audio TBN fwd+bwd)" if args.config == 4 and not args.forward_only
+            else f"clips/sec (config {args.config}{', forward only' if args.forward_only else ''})",
+            "value": round(value, 2), "unit": "clips/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE config 4: RGB+Flow+Audio async, attention off, 3 segments, 224x224 frames "
-                                   "+ 1.279 s (256x256) spectrogram, train step fwd+loss+bwd+clip+SGD",
+            "config": {"workload": C_["name"] + (" [forward only]" if args.forward_only and C_["train"] else ""),
                        "batch_per_gpu": B, "global_batch": B * world, "segments": n,
                        "parallelism": f"dp{world}" if world > 1 else "single"},
             "roofline": roofline,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.config == 4 and not args.forward_only:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
     if world > 1:
