@@ -418,13 +418,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
   const int pbeg = split * p.rows_per_split;
   const int pend = min(p.M, pbeg + p.rows_per_split);
 
-  f32x16 acc[MT][NT];
+  constexpr int KS = 4 / (MT * NT) > 0 ? 4 / (MT * NT) : 1;  // K-split accumulators per sub-tile (see the main loop)
+  f32x16 acc[MT][NT][KS];
 #pragma unroll
   for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+      for (int q = 0; q < KS; ++q)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][q][e] = 0.f;
 
   // VALU diet (the fp32 MFMA shares the VALU lanes: every VALU op costs MFMA time).  Lane l owns ONE pixel
   // row of the 16-row step (row = l >> 2) and the float4 columns {q, q+4, q+8, ...} (q = l & 3): the row is
@@ -489,18 +492,38 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
     store_tiles();
     __builtin_amdgcn_wave_barrier();
     if (it + 1 < nsteps) load_tiles(pbeg + ((it + 1) * 4 + wave) * KR);
+    // Fragments of k-pair kp+1 are read while k-pair kp multiplies (two register sets; the sched_group_barrier
+    // chain pins the DS-read group / MFMA group alternation).  Consecutive MFMAs rotate over FOUR independent
+    // accumulators: a dependent MFMA is only free right behind its producer or >= 4 MFMAs later -- alternating
+    // two accumulators halves the rate (scripts/ubench, conv_igemm_kernel) -- so tiles with fewer than four
+    // 32x32 sub-tiles split K over KS accumulators per sub-tile (summed before the cross-wave reduction).
+    float a[2][MT], bb[2][NT];
+    auto frag = [&](int buf, int kp) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i) a[buf][i] = At[(2 * kp + lhalf) * WA + i * 32 + lrow];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) bb[buf][j] = Bt[(2 * kp + lhalf) * WB + j * 32 + lrow];
+    };
+    frag(0, 0);
 #pragma unroll
     for (int kp = 0; kp < KR / 2; ++kp) {
-      float a[MT], bb[NT];
-#pragma unroll
-      for (int i = 0; i < MT; ++i) a[i] = At[(2 * kp + lhalf) * WA + i * 32 + lrow];
-#pragma unroll
-      for (int j = 0; j < NT; ++j) bb[j] = Bt[(2 * kp + lhalf) * WB + j * 32 + lrow];
+      if (kp + 1 < KR / 2) frag((kp + 1) & 1, kp + 1);
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bb[j], acc[i][j], 0, 0, 0);
+          acc[i][j][kp % KS] =
+              __builtin_amdgcn_mfma_f32_32x32x2f32(a[kp & 1][i], bb[kp & 1][j], acc[i][j][kp % KS], 0, 0, 0);
+    }
+    {
+      constexpr int NM = MT * NT;   // the (MT + NT) b32 fragment reads of a k-pair are 2 DS instructions
+      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+      for (int g = 0; g < KR / 2 - 2; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 2 * NM, 0);
     }
     __builtin_amdgcn_wave_barrier();
   }
@@ -516,7 +539,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int row = 8 * (e >> 2) + 4 * lhalf + (e & 3);
-        red[wave * 1024 + row * 32 + lrow] = acc[i][j][e];
+        float v = acc[i][j][0][e];
+#pragma unroll
+        for (int q = 1; q < KS; ++q) v += acc[i][j][q][e];
+        red[wave * 1024 + row * 32 + lrow] = v;
       }
       __syncthreads();
 #pragma unroll
