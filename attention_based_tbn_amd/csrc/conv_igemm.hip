@@ -557,20 +557,41 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
     }
 }
 
-__global__ void splitk_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int n4, int splits,
-                                     size_t slab4) {
+// Sums the split-K slabs of a weight gradient.  256 threads = (256 / SG) float4 outputs x SG slab lanes: lane g adds
+// slabs g, g+SG, ... (two independent chains), the SG partial sums are combined through LDS in fixed order
+// (deterministic).  SG = 16 for many slabs of a small matrix (the 7x7 stem: ~110 slabs of 57 KB) so that the
+// grid still covers the chip; SG = 4 otherwise.
+template <int SG>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, float* __restrict__ out,
+                                                            int n4, int splits, size_t slab4) {
+  constexpr int NO = 256 / SG;
+  __shared__ float4 red[256];
+  const int o = threadIdx.x % NO, g = threadIdx.x / NO;
+  const int i = blockIdx.x * NO + o;
   const float4* p4 = reinterpret_cast<const float4*>(part);
-  float4* o4 = reinterpret_cast<float4*>(out);
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += gridDim.x * blockDim.x) {
-    float4 a = p4[i];
-    for (int s = 1; s < splits; ++s) {
-      const float4 v = p4[(size_t)s * slab4 + i];
-      a.x += v.x;
-      a.y += v.y;
-      a.z += v.z;
-      a.w += v.w;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+  if (i < n4) {
+    int s = g;
+    for (; s + SG < splits; s += 2 * SG) {
+      const float4 u = p4[(size_t)s * slab4 + i], v = p4[(size_t)(s + SG) * slab4 + i];
+      a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
+      b.x += v.x; b.y += v.y; b.z += v.z; b.w += v.w;
     }
-    o4[i] = a;
+    if (s < splits) {
+      const float4 u = p4[(size_t)s * slab4 + i];
+      a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
+    }
+    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+  }
+  red[threadIdx.x] = a;
+  __syncthreads();
+  if (g == 0 && i < n4) {
+#pragma unroll
+    for (int k = 1; k < SG; ++k) {
+      const float4 v = red[k * NO + o];
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    reinterpret_cast<float4*>(out)[i] = a;
   }
 }
 
@@ -840,9 +861,10 @@ int tbn_launch_wgrad(WgradP p, int rowmode, float* dw, float* workspace, hipStre
   if (splits > 1) {
     const size_t n = (size_t)p.Cout * p.K;
     const int n4 = (int)(n / 4);
-    int grid = cdiv(n4, 256);
-    if (grid > 2048) grid = 2048;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, st, workspace, dw, n4, splits, n / 4);
+    if (splits >= 32 && n4 < 64 * 1024)
+      hipLaunchKernelGGL(splitk_reduce_kernel<16>, dim3(cdiv(n4, 16)), dim3(256), 0, st, workspace, dw, n4, splits, n / 4);
+    else
+      hipLaunchKernelGGL(splitk_reduce_kernel<4>, dim3(cdiv(n4, 64)), dim3(256), 0, st, workspace, dw, n4, splits, n / 4);
     TBN_CHECK_LAUNCH("splitk_reduce");
   }
   return TBN_OK;
@@ -852,5 +874,39 @@ int tbn_launch_weight_flip_transpose(const float* w, float* wt, int Cout, int ta
   hipLaunchKernelGGL(weight_flip_transpose_kernel, dim3(cdiv(Cin, 32), cdiv(Cout, 32), taps), dim3(256), 0, st, w,
                      wt, Cout, taps, Cin);
   TBN_CHECK_LAUNCH("weight_flip_transpose");
+  return TBN_OK;
+}
+
+// All layers of a backbone in ONE launch (the per-layer launches are ~4 us of pure latency each, 50 per
+// backward pass): the layer table rides in the kernel arguments, a workgroup finds its layer by a scalar scan.
+__global__ __launch_bounds__(256) void weight_flip_transpose_all_kernel(const float* __restrict__ w,
+                                                                        float* __restrict__ wt, FlipTab tab) {
+  __shared__ float tile[32][33];
+  int l = 0;
+  while (l + 1 < tab.n && (int)blockIdx.x >= tab.blk0[l + 1]) ++l;
+  const int Cout = tab.cout[l], Cin = tab.cin[l], taps = tab.taps[l];
+  const int tci = (Cin + 31) >> 5, tco = (Cout + 31) >> 5;
+  int b = blockIdx.x - tab.blk0[l];
+  const int ci0 = (b % tci) * 32;
+  b /= tci;
+  const int co0 = (b % tco) * 32, tap = b / tco;
+  const float* wl = w + tab.w_off[l];
+  float* wtl = wt + tab.w_off[l];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int i = ty; i < 32; i += 8) {
+    const int co = co0 + i, ci = ci0 + tx;
+    tile[i][tx] = (co < Cout && ci < Cin) ? wl[((size_t)co * taps + tap) * Cin + ci] : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int ci = ci0 + i, co = co0 + tx;
+    if (ci < Cin && co < Cout) wtl[((size_t)ci * taps + (taps - 1 - tap)) * Cout + co] = tile[tx][i];
+  }
+}
+
+int tbn_launch_weight_flip_transpose_all(const float* w, float* wt, const FlipTab& tab, hipStream_t st) {
+  if (tab.n == 0) return TBN_OK;
+  hipLaunchKernelGGL(weight_flip_transpose_all_kernel, dim3(tab.blk0[tab.n]), dim3(256), 0, st, w, wt, tab);
+  TBN_CHECK_LAUNCH("weight_flip_transpose_all");
   return TBN_OK;
 }

@@ -17,6 +17,7 @@
 #include <cstring>
 #include <cstdio>
 
+#include <cstdlib>
 #include "tbn_common.h"
 #include "tbn_kernels.h"
 #include "../../include/tbn_hip.h"
@@ -91,6 +92,7 @@ struct tbn_backbone_plan {
   size_t weight_floats, chan_floats;
   // workspace layout (float offsets unless noted)
   size_t x0_off, stats_off, partial_off, coef_off, wsplit_off, wt_off, wpack_off, dwpack_off;
+  FlipTab flip;  // data-gradient weights: one flip/transpose launch per backward pass
   size_t partial_floats, wsplit_floats, wt_floats;
   size_t argmax_bytes_off, total_bytes_train, total_bytes_eval;
   size_t eval_floats;
@@ -306,10 +308,21 @@ void plan_memory(tbn_backbone_plan* P) {
     if (c.need_dgrad) {
       const int Md = (int)(R * c.inH * c.inW);
       tbn_conv_pick_tile(Md, c.cin, c.k * c.k * c.cout, &c.d_mt, &c.d_nt);
-      size_t wt = (size_t)c.cout * c.k * c.k * c.cin;
-      if (wt > wtf) wtf = wt;
     }
   }
+  // flipped / transposed copy of every data-gradient weight, at the layer's own offset
+  wtf = P->weight_floats;
+  memset(&P->flip, 0, sizeof(P->flip));
+  for (auto& c : P->convs)
+    if (c.need_dgrad && P->flip.n < 64) {
+      FlipTab& f = P->flip;
+      f.w_off[f.n] = (int)c.w_off;
+      f.cout[f.n] = (short)c.cout;
+      f.cin[f.n] = (short)c.cin;
+      f.taps[f.n] = (short)(c.k * c.k);
+      f.blk0[f.n + 1] = f.blk0[f.n] + cdiv(c.cin, 32) * cdiv(c.cout, 32) * c.k * c.k;
+      ++f.n;
+    }
   P->partial_floats = partial;
   P->wsplit_floats = wsplit;
   P->wt_floats = wtf;
@@ -354,6 +367,15 @@ int tbn_backbone_plan_create(int in_channels, int frames, int height, int width,
   P->H = height;
   P->W = width;
   build_graph(P);
+  {
+    int nd = 0;
+    for (auto& c : P->convs) nd += c.need_dgrad ? 1 : 0;
+    if (nd > 64) {
+      delete P;
+      tbn_set_error("plan_create: %d data-gradient layers exceed the flip table (64)", nd);
+      return TBN_ERR_UNSUPPORTED;
+    }
+  }
   plan_memory(P);
   *out = P;
   return TBN_OK;
@@ -624,7 +646,7 @@ int tbn_backbone_autotune(tbn_backbone_plan* P, int training, const tbn_backbone
       } else {
         p.in = ws + c.y_off;
         p.in_ld = c.cout;
-        p.wt = ws + P->wt_off;
+        p.wt = ws + P->wt_off + c.w_off;
         p.H = c.outH;
         p.W = c.outW;
         p.OH = c.inH;
@@ -710,6 +732,7 @@ int tbn_backbone_backward(const tbn_backbone_plan* P, const float* dfeatures, co
     return buf == P->out_buf ? dfeatures : ws + P->bufs[buf].doff;
   };
 
+  TBN_TRY(tbn_launch_weight_flip_transpose_all(prm->weight, ws + P->wt_off, P->flip, st));
   for (int oi = (int)P->ops.size() - 1; oi >= 0; --oi) {
     const Op& o = P->ops[oi];
     if (o.kind == 1) {
@@ -794,8 +817,7 @@ int tbn_backbone_backward(const tbn_backbone_plan* P, const float* dfeatures, co
     // data gradient: conv of dy with flipped / transposed weights (zero-insertion for stride 2)
     if (c.need_dgrad) {
       tbn_prof_label(("dgrad " + c.names[c.nparts - 1]).c_str());
-      float* wt = ws + P->wt_off;
-      TBN_TRY(tbn_launch_weight_flip_transpose(prm->weight + c.w_off, wt, c.cout, c.k * c.k, c.cin, st));
+      const float* wt = ws + P->wt_off + c.w_off;
       ConvP p;
       memset(&p, 0, sizeof(p));
       p.in = y;

@@ -15,13 +15,22 @@ static inline int ew_grid(size_t items) {
   return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g));
 }
 
+// Stencil kernels re-read their neighbours' rows: workgroups b, b+8, ... share an XCD (and its L2), so the
+// bijective remap hands every XCD a CONTIGUOUS run of workgroup ids -- a row is then fetched into one L2, not
+// into all eight (measured: 3x the algorithmic HBM reads without it).
+__device__ __forceinline__ size_t xcd_block_id() {
+  const unsigned nb = gridDim.x, bid = blockIdx.x;
+  const unsigned q8 = nb >> 3, r8 = nb & 7, xcd = bid & 7, idx = bid >> 3;
+  return (size_t)((xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx);
+}
+
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ in, int in_ld,
                                                           float* __restrict__ out, int out_ld,
                                                           uint8_t* __restrict__ argmax, int N, int H, int W, int C,
                                                           int OH, int OW, int stride, int pad) {
   const int G = C >> 2;
   const size_t total = (size_t)N * OH * OW * G;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+  for (size_t i = xcd_block_id() * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
     const int g = (int)(i % G);
     size_t pix = i / G;
     const int ox = (int)(pix % OW);
@@ -68,7 +77,7 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
                                                           int C, int OH, int OW, int stride, int pad, int accumulate) {
   const int G = C >> 2;
   const size_t total = (size_t)N * H * W * G;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+  for (size_t i = xcd_block_id() * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
     const int g = (int)(i % G);
     size_t pix = i / G;
     const int ix = (int)(pix % W);
@@ -118,7 +127,7 @@ __global__ __launch_bounds__(256) void avgpool3_kernel(const float* __restrict__
                                                        int accumulate) {
   const int G = C >> 2;
   const size_t total = (size_t)N * H * W * G;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+  for (size_t i = xcd_block_id() * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
     const int g = (int)(i % G);
     size_t pix = i / G;
     const int x = (int)(pix % W);
@@ -217,20 +226,31 @@ int tbn_launch_spatial_mean_bwd(const float* dout, int dout_ld, float* din, int 
 }
 
 // NCHW (reference tensor layout, model.py:211-213) -> NHWC padded to Cp channels (zeros)
+template <int Q>  // Q = Cp / 4 float4 stores per pixel
 __global__ __launch_bounds__(256) void nchw_to_nhwc_pad_kernel(const float* __restrict__ in, float* __restrict__ out,
-                                                               int N, int C, int H, int W, int Cp) {
+                                                               int N, int C, int H, int W) {
   const size_t hw = (size_t)H * W, total = (size_t)N * hw;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
     const size_t n = i / hw, p = i - n * hw;
-    float* o = out + i * Cp;
-    for (int c = 0; c < Cp; ++c) o[c] = c < C ? in[(n * C + c) * hw + p] : 0.f;
+    const float* src = in + n * C * hw + p;   // lanes read consecutive pixels of one plane: coalesced
+    float v[4 * Q];
+#pragma unroll
+    for (int c = 0; c < 4 * Q; ++c) v[c] = c < C ? src[(size_t)c * hw] : 0.f;
+    float4* o = reinterpret_cast<float4*>(out + i * (4 * Q));
+#pragma unroll
+    for (int q = 0; q < Q; ++q) o[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
   }
 }
 
 int tbn_launch_nchw_to_nhwc_pad(const float* in, float* out, int N, int C, int H, int W, int Cp, hipStream_t st) {
-  TBN_REQUIRE(Cp >= C && Cp % 4 == 0, "nchw_to_nhwc_pad: Cp must be >= C and a multiple of 4");
-  hipLaunchKernelGGL(nchw_to_nhwc_pad_kernel, dim3(ew_grid((size_t)N * H * W)), dim3(256), 0, st, in, out, N, C, H, W,
-                     Cp);
+  TBN_REQUIRE(Cp >= C && Cp % 4 == 0 && Cp <= 16, "nchw_to_nhwc_pad: Cp must be >= C, a multiple of 4 and <= 16");
+  const dim3 grid(ew_grid((size_t)N * H * W));
+  switch (Cp / 4) {
+    case 1: hipLaunchKernelGGL(nchw_to_nhwc_pad_kernel<1>, grid, dim3(256), 0, st, in, out, N, C, H, W); break;
+    case 2: hipLaunchKernelGGL(nchw_to_nhwc_pad_kernel<2>, grid, dim3(256), 0, st, in, out, N, C, H, W); break;
+    case 3: hipLaunchKernelGGL(nchw_to_nhwc_pad_kernel<3>, grid, dim3(256), 0, st, in, out, N, C, H, W); break;
+    default: hipLaunchKernelGGL(nchw_to_nhwc_pad_kernel<4>, grid, dim3(256), 0, st, in, out, N, C, H, W); break;
+  }
   TBN_CHECK_LAUNCH("nchw_to_nhwc_pad");
   return TBN_OK;
 }

@@ -72,6 +72,14 @@ void tbn_wgrad_plan(int M, int Cout, int Cin, int taps, int* mt, int* nt, int* s
 size_t tbn_wgrad_workspace_floats(int M, int Cout, int Cin, int taps);
 int tbn_launch_wgrad(WgradP p, int rowmode, float* dw, float* workspace, hipStream_t st);
 int tbn_launch_weight_flip_transpose(const float* w, float* wt, int Cout, int taps, int Cin, hipStream_t st);
+// layer table of the one-launch flip/transpose of every data-gradient weight of a backbone (kernel argument)
+struct FlipTab {
+  int n;
+  int w_off[64];     // float offset of the layer inside the flat weight array (same offset in the flipped copy)
+  short cout[64], cin[64], taps[64];
+  int blk0[65];      // first workgroup of each layer; blk0[n] = grid size
+};
+int tbn_launch_weight_flip_transpose_all(const float* w, float* wt, const FlipTab& tab, hipStream_t st);
 
 // bn.hip
 int tbn_launch_bn_stats(const float* y, int ld, int P, int C, float* partial, int* nparts, hipStream_t st);
