@@ -70,6 +70,23 @@ def collect_profile():
     return out
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the newest committed PMC summary (separate rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE passes of this same command, scripts/pmc_traffic.py); None if there is none."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if not files:
+        return None
+    try:
+        with open(files[-1]) as f:
+            k = json.load(f)["kernels"].get(kernel)
+        return None if k is None else {"hbm_bytes_per_launch": k["hbm_bytes_per_launch"],
+                                        "read": k["hbm_read_bytes_per_launch"], "write": k["hbm_write_bytes_per_launch"],
+                                        "source": os.path.relpath(files[-1], ROOT)}
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def cpu_baseline(seconds_budget=25.0):
     """the CPU oracle (torch-CPU restatement of the reference path) on this box's host cores:
     same config-4 graph and full-size inputs, B=2 clips x 3 segments, fwd+loss+bwd"""
@@ -118,7 +135,9 @@ def main():
     ap.add_argument("--no-multi-stream", action="store_true", help="diagnostic: run the modality backbones on one stream")
     ap.add_argument("--no-aux-stream", action="store_true", help="diagnostic: weight gradients on the backbone's own stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--profile-every", type=int, default=20, help="bracket conv-GEMM launches with HIP events on every k-th timed step")
+    ap.add_argument("--profile-every", type=int, default=1 << 30,
+                    help="bracket conv-GEMM launches with HIP events on every k-th timed step (default: the first "
+                         "timed step only; 0 = never).  Profiled steps run single-stream, see DESIGN.md")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -227,7 +246,8 @@ def main():
             ach = top["flops"] / (top["ms"] * 1e-3) / 1e12
             tot_ms, tot_fl = sum(e["ms"] for e in prof), sum(e["flops"] for e in prof)
             roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                        "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": (pmc_traffic(top["kernel"]) or {}).get("hbm_bytes_per_launch"),
+                        "traffic_detail": pmc_traffic(top["kernel"]),
                         "kernel": top["kernel"], "launches": top["launches"],
                         "avg_launch_us": round(1e3 * top["ms"] / top["launches"], 2),
                         "alg_gflop_per_launch": round(top["flops"] / top["launches"] / 1e9, 4),
