@@ -27,6 +27,10 @@ class BackboneGrads(C.Structure):
                 ("aux_stream", c_fp)]
 
 
+class OptTensor(C.Structure):
+    _fields_ = [("param", c_fp), ("grad", c_fp), ("momentum", c_fp), ("count", c_sz)]
+
+
 # name -> (restype, argtypes); every symbol declared in include/tbn_hip.h
 SIGNATURES = {
     "tbn_version": (c_i, []),
@@ -85,6 +89,12 @@ SIGNATURES = {
     "tbn_stft_twiddle_floats": (c_sz, []),
     "tbn_stft_make_twiddle": (c_i, [c_fp]),
     "tbn_stft_logpower": (c_i, [c_fp, c_i, c_i, c_fp, c_fp, c_f, c_fp]),
+    "tbn_opt_num_partials": (c_i, [C.POINTER(OptTensor), c_i]),
+    "tbn_opt_sqnorm_partials": (c_i, [C.POINTER(OptTensor), c_i, c_fp, c_fp]),
+    "tbn_opt_clip_coef": (c_i, [c_fp, c_i, c_f, c_fp, c_fp, c_fp]),
+    "tbn_opt_scale_grads": (c_i, [C.POINTER(OptTensor), c_i, c_fp, c_fp]),
+    "tbn_opt_sgd_step": (c_i, [C.POINTER(OptTensor), c_i, c_f, c_f, c_f, c_fp, c_fp]),
+    "tbn_topk_correct": (c_i, [c_fp, c_i, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp]),
 }
 
 _lib = None

@@ -219,6 +219,21 @@ class BNInception(nn.Module):
         n0 = self.first_bn_channels
         return flat_first.data[a:b] if b <= n0 else flat_rest.data[a - n0:b - n0]
 
+    def reference_param_views(self, flat):
+        """(key, view) pairs of the four PARAMETER kinds in the reference's order, taken from `flat` =
+        {attribute name: tensor shaped like that flat parameter} -- e.g. the momentum buffers of the optimiser"""
+        n0 = self.first_bn_channels
+        for name in self._order:
+            L = self._layers[name]
+            n = L["cout"] * L["k"] * L["k"] * L["cin"]
+            a, b = L["c_off"], L["c_off"] + L["cout"]
+            yield name + ".weight", flat["flat_weight"][L["w_off"]:L["w_off"] + n].view(
+                L["cout"], L["k"], L["k"], L["cin"]).permute(0, 3, 1, 2)
+            yield name + ".bias", flat["flat_bias"][a:b]
+            first = b <= n0
+            yield name + "_bn.weight", (flat["bn_weight_first"][a:b] if first else flat["bn_weight_rest"][a - n0:b - n0])
+            yield name + "_bn.bias", (flat["bn_bias_first"][a:b] if first else flat["bn_bias_rest"][a - n0:b - n0])
+
     def named_reference_tensors(self):
         """(key, tensor view) pairs in the reference's state_dict order"""
         for i, name in enumerate(self._order):

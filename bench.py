@@ -163,8 +163,9 @@ def main():
     core = getattr(model, "module", model)
     bases = [getattr(core, "Base_" + m) for m in modality]
     params = [p for p in model.parameters() if p.requires_grad]
-    opt = torch.optim.SGD(params, lr=cfg.train.optim.lr, momentum=cfg.train.optim.momentum,
-                          weight_decay=cfg.train.optim.weight_decay)
+    from attention_based_tbn_amd.core.utils import FusedSGD
+    opt = FusedSGD(params, lr=cfg.train.optim.lr, momentum=cfg.train.optim.momentum,
+                   weight_decay=cfg.train.optim.weight_decay)
     B = args.batch_per_gpu or C_["batch"]
     n = cfg.train.num_segments if C_["train"] else cfg.test.num_segments
     inp, tgt = synthetic_batch(B, n, device, seed=rank, modality=modality)   # clips are sharded by rank: no data-path collective
@@ -192,8 +193,7 @@ def main():
         out = model(inp)
         loss, _ = model.get_loss(criterion, tgt, out, 0)
         loss["total"].backward()              # N>1: gradient all-reduce is issued inside backward, waited at its end
-        torch.nn.utils.clip_grad_norm_(params, cfg.train.clip_grad)
-        opt.step()
+        opt.step(clip_grad=cfg.train.clip_grad)   # clip_grad_norm_(20) + SGD(momentum) in three HIP launches
         return loss["total"]
 
     multi, aux = not args.no_multi_stream, not args.no_aux_stream

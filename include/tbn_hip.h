@@ -214,6 +214,36 @@ int tbn_stft_make_twiddle(float* host_buffer);
 int tbn_stft_logpower(const float* wave, int nseg, int len, const float* twiddle, float* spec, float eps,
                       void* stream);
 
+/* ---- train-step shell and metrics (the steps right after the path) -- */
+/* Multi-tensor clip_grad_norm_ + SGD(momentum) of reference core/tools/train.py:82-94,190-202
+ * (torch.nn.utils.clip_grad_norm_ norm_type 2; torch.optim.SGD dampening 0, no nesterov).  All tensors of a
+ * call ride in one launch (16-byte aligned tensors move 16 B per lane, others 4 B); `momentum` buffers start as zeros (first step
+ * m = d, as torch's clone).  Nothing is read back: the clip coefficient stays on the device. */
+#define TBN_OPT_MAX_TENSORS 48
+typedef struct tbn_opt_tensor {
+  void* param;        /* fp32 parameter (may be NULL for the norm / scale entries) */
+  const void* grad;   /* fp32 gradient */
+  void* momentum;     /* fp32 momentum buffer (NULL when momentum == 0) */
+  size_t count;       /* elements */
+} tbn_opt_tensor;
+/* number of per-workgroup partial sums tbn_opt_sqnorm_partials writes for these tensors */
+int tbn_opt_num_partials(const tbn_opt_tensor* tensors, int num_tensors);
+/* partials[i] = sum of squares of one 16384-element chunk of the gradients */
+int tbn_opt_sqnorm_partials(const tbn_opt_tensor* tensors, int num_tensors, float* partials, void* stream);
+/* total_norm[0] = sqrt(sum partials) (fp64, fixed order); coef[0] = min(1, max_norm / (total_norm + 1e-6)) */
+int tbn_opt_clip_coef(const float* partials, int num_partials, float max_norm, float* total_norm, float* coef,
+                      void* stream);
+/* grad *= coef[0] in place (what clip_grad_norm_ leaves behind; skipped when coef == 1) */
+int tbn_opt_scale_grads(const tbn_opt_tensor* tensors, int num_tensors, const float* coef, void* stream);
+/* d = grad * grad_scale[0] (1 if NULL) + weight_decay * p ; m = momentum * m + d ; p -= lr * m */
+int tbn_opt_sgd_step(const tbn_opt_tensor* tensors, int num_tensors, float lr, float momentum, float weight_decay,
+                     const float* grad_scale, void* stream);
+/* Metric._get_correct_score (core/utils/metric.py:137-157): scores (batch, classes) pitch scores_ld, target int64.
+ * correct (k, batch) uint8 = [j-th ranked class == target]; pred (k, batch) int64 ranked classes (may be NULL);
+ * conf_mat (classes, classes) float, conf_mat[target][top1] += 1 (may be NULL).  Ties rank the lower index first. */
+int tbn_topk_correct(const float* scores, int scores_ld, const long long* target, int batch, int classes, int k,
+                     unsigned char* correct, long long* pred, float* conf_mat, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,157 @@
+"""GPU parity of the train-step shell and metrics (through the C-ABI) against the oracle and the fixtures made by
+torch's own optimiser / the reference's Metric (tests/golden/make_golden_trainstep.py)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import trainstep as ot
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+DEV = "cuda"
+
+
+def _load():
+    z = np.load(os.path.join(GOLD, "trainstep.npz"))
+    return z, [torch.nn.Parameter(torch.from_numpy(z["p0_%d" % i].astype(np.float32)).to(DEV)) for i in range(3)]
+
+
+@pytest.mark.parametrize("fused_clip", [False, True])
+def test_fused_sgd_and_clip_match_torch_golden(fused_clip):
+    from attention_based_tbn_amd.core.utils import FusedSGD, clip_grad_norm_
+    z, params = _load()
+    frozen = torch.nn.Parameter(torch.ones(7, device=DEV))     # no gradient: must stay untouched
+    opt = FusedSGD(params + [frozen], 0.01, momentum=0.9, weight_decay=0.0005)
+    sched = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=[2], gamma=0.1)
+    for s in range(3):
+        opt.zero_grad()
+        for i, p in enumerate(params):
+            p.grad = torch.from_numpy(z["g%d_%d" % (s, i)].astype(np.float32)).to(DEV)
+        if fused_clip:
+            opt.step(clip_grad=20)
+            total = opt.last_total_norm
+        else:
+            total = clip_grad_norm_(params + [frozen], 20)
+            if s == 1:
+                for i, p in enumerate(params):
+                    np.testing.assert_allclose(p.grad.cpu().numpy(), z["gclip1_%d" % i], rtol=2e-6, atol=0)
+            opt.step()
+        assert abs(total.item() - z["norm%d" % s]) <= 2e-6 * z["norm%d" % s]
+        sched.step()
+        assert abs(opt.param_groups[0]["lr"] - z["lr%d" % s]) < 1e-9
+        for i, p in enumerate(params):
+            np.testing.assert_allclose(p.detach().cpu().numpy(), z["p%d_%d" % (s + 1, i)], rtol=2e-6, atol=2e-7)
+    for i, p in enumerate(params):
+        np.testing.assert_allclose(opt.state[p]["momentum_buffer"].cpu().numpy(), z["m3_%d" % i], rtol=4e-6, atol=2e-7)
+    assert torch.equal(frozen.detach().cpu(), torch.ones(7))
+    # torch's state_dict layout, so torch.optim.SGD can resume from it
+    ref = torch.optim.SGD(params + [frozen], 0.01, momentum=0.9, weight_decay=0.0005)
+    ref.load_state_dict(opt.state_dict())
+    assert torch.equal(ref.state[params[2]]["momentum_buffer"], opt.state[params[2]]["momentum_buffer"])
+
+
+def test_fused_sgd_many_tensors_vs_oracle():
+    """more tensors than one launch table holds (48), odd sizes, no momentum / no weight decay variants"""
+    from attention_based_tbn_amd.core.utils import FusedSGD
+    g = torch.Generator().manual_seed(3)
+    sizes = [1 + (i * 977) % 5003 for i in range(61)]
+    for mom, wd in ((0.0, 0.0), (0.9, 0.0), (0.5, 0.01)):
+        ps = [torch.randn(n, generator=g) for n in sizes]
+        params = [torch.nn.Parameter(p.clone().to(DEV)) for p in ps]
+        opt = FusedSGD(params, 0.05, momentum=mom, weight_decay=wd)
+        want = [p.numpy().copy() for p in ps]
+        bufs = [None] * len(ps)
+        for step in range(2):
+            gs = [torch.randn(n, generator=g) for n in sizes]
+            for p, gr in zip(params, gs):
+                p.grad = gr.to(DEV)
+            opt.step()
+            for i in range(len(ps)):
+                want[i], bufs[i] = ot.sgd_step(want[i], gs[i].numpy(), bufs[i], 0.05, mom, wd)
+        for i, p in enumerate(params):
+            np.testing.assert_allclose(p.detach().cpu().numpy(), want[i], rtol=2e-6, atol=2e-7)
+
+
+def test_optimizer_rejects_cpu_tensors():
+    from attention_based_tbn_amd._lib import TbnHipError
+    from attention_based_tbn_amd.core.utils import FusedSGD, clip_grad_norm_
+    p = torch.nn.Parameter(torch.ones(8))
+    p.grad = torch.ones(8)
+    with pytest.raises(TbnHipError):
+        clip_grad_norm_([p], 1.0)
+    with pytest.raises(TbnHipError):
+        FusedSGD([p], 0.1).step()
+
+
+def test_metric_matches_reference_golden():
+    from attention_based_tbn_amd.config import load_config
+    from attention_based_tbn_amd.core.utils import Metric
+    doc = json.load(open(os.path.join(GOLD, "metric.json")))
+    cfg = load_config(doc["overrides"])
+    m = Metric(cfg, 2, device=torch.device(DEV))
+    for b in doc["batches"]:
+        out = {"verb": torch.tensor(b["verb"], device=DEV), "noun": torch.tensor(b["noun"], device=DEV),
+               "weights": torch.zeros(b["B"] * 3, 1, 8, device=DEV)}
+        tgt = {"class": {"verb": torch.tensor(b["t_verb"], device=DEV), "noun": torch.tensor(b["t_noun"], device=DEV)}}
+        m.set_metrics(out, tgt, b["B"], {k: torch.tensor(v) for k, v in b["loss"].items()})
+    loss, acc, cm = m.get_metrics()
+    exp = doc["expected"]
+    assert acc == exp["accuracy"]
+    for k, v in exp["loss"].items():
+        assert abs(loss[k] - v) <= 1.1e-5
+    for k in ("verb", "noun"):
+        assert torch.equal(cm[k].cpu(), torch.tensor(exp["conf_mat"][k]))
+
+
+@pytest.mark.parametrize("B,C,k", [(1, 2, 1), (33, 125, 5), (512, 352, 5), (9, 1000, 10)])
+def test_topk_correct_vs_oracle_with_ties(B, C, k):
+    from attention_based_tbn_amd.core.utils.metric import get_correct_score
+    g = torch.Generator().manual_seed(B * 7 + C)
+    scores = torch.randn(B, C, generator=g)
+    scores[:, ::3] = scores[:, :1].clone()    # many exact ties: lower class index ranks first
+    target = torch.randint(0, C, (B,), generator=g)
+    corr, cm = get_correct_score(scores.to(DEV), target.to(DEV), [1, k])
+    wc, wm = ot.topk_correct(scores.numpy(), target.numpy(), k)
+    assert np.array_equal(corr.cpu().numpy(), wc)
+    assert np.array_equal(cm.cpu().numpy(), wm)
+    assert cm.sum().item() == B               # every sample lands in exactly one cell (checksum property)
+
+
+def test_checkpoint_roundtrip_reference_layout(tmp_path):
+    """save_checkpoint writes the reference's file layout (per-layer keys, per-layer optimizer slots); loading it
+    back restores parameters and the flat momentum buffers bit for bit"""
+    from attention_based_tbn_amd.config import get_modality, load_config
+    from attention_based_tbn_amd.core.models import build_model
+    from attention_based_tbn_amd.core.utils import FusedSGD, load_checkpoint, save_checkpoint
+    from attention_based_tbn_amd.core.utils.misc import reference_parameter_names
+    cfg = load_config(["data.flow.enable=False", "data.audio.enable=False", "model.attention.enable=False"])
+    mod = get_modality(cfg)
+    torch.manual_seed(0)
+    model, crit, _ = build_model(cfg, mod, torch.device(DEV))
+    model.train()
+    opt = FusedSGD(model.parameters(), 0.01, momentum=0.9, weight_decay=0.0005)
+    x = {"RGB": torch.rand(2, 3, 3, 64, 64, device=DEV) - 0.45}
+    tgt = {"class": {"verb": torch.tensor([1, 2], device=DEV), "noun": torch.tensor([3, 4], device=DEV)}}
+    loss, _ = model.get_loss(crit, tgt, model(x), 0)
+    loss["total"].backward()
+    opt.step(clip_grad=20)
+    fn = str(tmp_path / "ck.pth")
+    save_checkpoint(model, opt, 3, [1.0], [2.0], [3.0], None, 1, filename=fn)
+    data = torch.load(fn, map_location="cpu")
+    names = reference_parameter_names(model)
+    assert list(data.keys()) == ["epoch", "train_loss", "validation_loss", "validation_accuracy", "optimizer", "model"]
+    assert data["optimizer"]["param_groups"][0]["params"] == list(range(len(names)))
+    assert data["model"]["Base_RGB.conv1_7x7_s2.weight"].shape == (64, 3, 7, 7)
+    assert data["optimizer"]["state"][0]["momentum_buffer"].shape == (64, 3, 7, 7)
+    torch.manual_seed(1)
+    model2, _, _ = build_model(cfg, mod, torch.device(DEV))
+    opt2 = FusedSGD(model2.parameters(), 0.5, momentum=0.1)
+    load_checkpoint(fn, model2, opt2)
+    for (n1, p1), (n2, p2) in zip(model.named_parameters(), model2.named_parameters()):
+        assert torch.equal(p1, p2), n1
+        b1, b2 = opt.state.get(p1, {}).get("momentum_buffer"), opt2.state.get(p2, {}).get("momentum_buffer")
+        assert (b1 is None and b2 is None) or torch.equal(b1, b2), n1
+    assert opt2.param_groups[0]["lr"] == 0.01 and opt2.param_groups[0]["momentum"] == 0.9
