@@ -71,15 +71,15 @@ hipEvent_t prof_event() {
     g_prof_pool.pop_back();
     return e;
   }
-  hipEvent_t e;
-  hipEventCreate(&e);
+  hipEvent_t e = nullptr;
+  (void)hipEventCreate(&e);   // a failed create leaves nullptr: the record / elapsed calls below then report 0 ms
   return e;
 }
 void prof_collect() {
   for (auto& r : g_prof_recs) {
-    hipEventSynchronize(r.b);
+    (void)hipEventSynchronize(r.b);
     float ms = 0.f;
-    hipEventElapsedTime(&ms, r.a, r.b);
+    (void)hipEventElapsedTime(&ms, r.a, r.b);
     ProfAgg& a = g_prof_agg[g_prof_names[r.name]];
     a.launches += 1;
     a.ms += ms;
@@ -111,7 +111,7 @@ void tbn_prof_begin(const char* kernel, double flops, hipStream_t st) {
   r.flops = flops;
   r.a = prof_event();
   r.b = prof_event();
-  hipEventRecord(r.a, st);
+  (void)hipEventRecord(r.a, st);
   g_prof_recs.push_back(r);
   g_prof_open = (int)g_prof_recs.size() - 1;
 }
@@ -123,7 +123,7 @@ void tbn_prof_label(const char* label) {
 void tbn_prof_end(hipStream_t st) {
   if (!g_prof_on) return;
   std::lock_guard<std::mutex> lk(g_prof_mu);
-  if (g_prof_open >= 0) hipEventRecord(g_prof_recs[g_prof_open].b, st);
+  if (g_prof_open >= 0) (void)hipEventRecord(g_prof_recs[g_prof_open].b, st);
   g_prof_open = -1;
 }
 

@@ -151,7 +151,6 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  const int cps = p.Cin >> 5;  // 32-float chunks per tap
   const int ksteps = p.K >> 5;
   float4 ra[AR], rb[NT];
   const unsigned b_row = (unsigned)(n0 + r0) * (unsigned)p.Krow * 4u + (unsigned)c4 * 16u;

@@ -696,8 +696,8 @@ int tbn_backbone_autotune(tbn_backbone_plan* P, int training, const tbn_backbone
     }
     if (rc != TBN_OK) break;
   }
-  hipEventDestroy(e0);
-  hipEventDestroy(e1);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
   return rc;
 }
 

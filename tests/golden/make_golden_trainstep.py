@@ -126,8 +126,38 @@ def scores():
     print("scores.json", len(expected["results"]))
 
 
+
+
+def priors():
+    """reference Video_Dataset._get_attn_weights (dataset.py:534-575) on seeded spectrograms; cv2.getGaussianKernel
+    (absent from the image) is stubbed with the restated closed form, as in make_golden.py"""
+    sys.path.insert(0, HERE)
+    from make_golden import install_stubs      # the same cv2 / torchvision / librosa stand-ins as the model fixtures
+    install_stubs()
+    sys.path.insert(0, REF)
+    import core.dataset.dataset as rds
+    rng = np.random.RandomState(4)
+    doc = {"cases": []}
+    for audio_length, W in ((1.279, 256), (2.1, 420), (4.0, 800), (0.64, 128)):
+        for prior_type in ("gaussian", "uniform", "loud"):
+            for rep in range(3 if prior_type == "loud" else 1):
+                ds = object.__new__(rds.Video_Dataset)
+                ds.cfg = load_config([f"model.attention.prior_type={prior_type}"])
+                ds.audio_length = audio_length
+                spec_ = rng.randn(16, W).astype(np.float32)
+                spec_[:, rng.randint(0, W)] += 9.0          # a clear loudest window somewhere
+                out = ds._get_attn_weights(spec_, 0, 0.0)
+                # the spectrogram is not stored: tests regenerate it from RandomState(4) with the same calls
+                doc["cases"].append({"audio_length": audio_length, "prior_type": prior_type, "W": W,
+                                     "expected": out.numpy().astype(np.float64).tolist()})
+    with open(os.path.join(HERE, "priors.json"), "w") as f:
+        json.dump(doc, f)
+    print("priors.json", len(doc["cases"]))
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
     trainstep()
     metric()
     scores()
+    priors()

@@ -85,3 +85,20 @@ def test_reference_parameter_names_and_optimizer_state_roundtrip():
     assert back["param_groups"][0]["params"] == list(range(len(names)))
     for i, n in enumerate(names):
         assert torch.equal(back["state"][i]["momentum_buffer"], ref_state["state"][i]["momentum_buffer"]), n
+
+
+def test_attention_priors_match_reference():
+    """gaussian / uniform / loud priors (dataset.py:534-575) on the generator's seeded spectrograms"""
+    from attention_based_tbn_amd.core.dataset import attention_prior
+    doc = json.load(open(os.path.join(GOLD, "priors.json")))
+    rng = np.random.RandomState(4)
+    kinds = set()
+    for c in doc["cases"]:
+        spec = rng.randn(16, c["W"]).astype(np.float32)
+        spec[:, rng.randint(0, c["W"])] += 9.0
+        got = attention_prior(spec, c["audio_length"], c["prior_type"])
+        exp = torch.tensor(c["expected"], dtype=torch.float64).float()
+        assert got.dtype == torch.float32 and got.shape == exp.shape
+        assert torch.equal(got, exp), (c["prior_type"], c["audio_length"])
+        kinds.add(c["prior_type"])
+    assert kinds == {"gaussian", "uniform", "loud"}
