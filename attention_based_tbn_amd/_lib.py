@@ -95,6 +95,7 @@ SIGNATURES = {
     "tbn_opt_scale_grads": (c_i, [C.POINTER(OptTensor), c_i, c_fp, c_fp]),
     "tbn_opt_sgd_step": (c_i, [C.POINTER(OptTensor), c_i, c_f, c_f, c_f, c_fp, c_fp]),
     "tbn_topk_correct": (c_i, [c_fp, c_i, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp]),
+    "tbn_frames_to_tensor": (c_i, [c_fp] + [c_i] * 16 + [c_fp, c_fp, c_i, c_i, c_fp, c_fp]),
 }
 
 _lib = None

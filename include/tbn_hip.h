@@ -244,6 +244,20 @@ int tbn_opt_sgd_step(const tbn_opt_tensor* tensors, int num_tensors, float lr, f
 int tbn_topk_correct(const float* scores, int scores_ld, const long long* target, int batch, int classes, int k,
                      unsigned char* correct, long long* pred, float* conf_mat, void* stream);
 
+/* ---- on-device visual input pipeline (the step right before the path) ---- */
+/* MultiScaleCrop / Rescale (cv2.resize INTER_LINEAR, 8-bit fixed point) -> CenterCrop / crop -> RandomHorizontalFlip
+ * -> Stack -> ToTensor (/255) -> Normalize of reference core/dataset/transform.py:9-543 as composed by
+ * core/utils/create_dataloader.py:19-81, in one pass over the pixels.  frames: (n_img, height, width, channels)
+ * uint8 on the device.  The source box (box_*) is resized to resized_w x resized_h (equal sizes: no interpolation),
+ * the window (crop_x, crop_y, out_w, out_h) of that is taken, flipped horizontally if `flip`; `stack` consecutive
+ * single/multi-channel images form the channels of one sample; out: (n_img/stack, channels*stack, out_h, out_w)
+ * fp32 = ((v [/255]) - mean[c % n_stat]) / std[c % n_stat] (n_stat = 0: no normalisation).  The random choices
+ * (crop box, flip) are the caller's: same host RNG draws as the reference. */
+int tbn_frames_to_tensor(const unsigned char* frames, int n_img, int height, int width, int channels, int box_x,
+                         int box_y, int box_w, int box_h, int resized_w, int resized_h, int crop_x, int crop_y,
+                         int out_w, int out_h, int flip, int stack, const float* mean, const float* std_dev,
+                         int n_stat, int div255, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

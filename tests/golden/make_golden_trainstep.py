@@ -155,9 +155,81 @@ def priors():
     print("priors.json", len(doc["cases"]))
 
 
+def transforms():
+    """reference get_transforms() pipelines (create_dataloader.py:19-81 -> transform.py) on seeded uint8 frames.
+    cv2 is absent: `cv2.resize` is stubbed with oracle.transform.resize_linear_u8 (the restated OpenCV INTER_LINEAR),
+    so the fixture pins crop-box sampling, draw order, flip, Stack, ToTensor and Normalize -- not the interpolation."""
+    import types
+    sys.path.insert(0, HERE)
+    from make_golden import install_stubs
+    install_stubs()
+    import cv2
+    from oracle.transform import resize_linear_u8
+    cv2.resize = lambda img, dsize, interpolation=None: resize_linear_u8(img, dsize[0], dsize[1])
+    tvt = sys.modules["torchvision"].transforms
+
+    class Compose:                       # torchvision.transforms.Compose: apply in order
+        def __init__(self, ts):
+            self.transforms = ts
+
+        def __call__(self, x):
+            for t in self.transforms:
+                x = t(x)
+            return x
+    tvt.Compose = Compose
+    sys.modules["torchvision.transforms"].Compose = Compose
+    sys.path.insert(0, REF)
+    spec = importlib.util.spec_from_file_location("ref_cdl", os.path.join(REF, "core/utils/create_dataloader.py"))
+    try:
+        cdl = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(cdl)
+        get_transforms = cdl.get_transforms
+    except Exception as e:               # the module also imports the DataLoader plumbing; fall back to the classes
+        print("create_dataloader import failed (%s): composing the reference classes as its lines 19-81 do" % e)
+        rt = ref_module("core/dataset/transform.py")
+
+        def get_transforms(cfg, modality, mode="test"):
+            out = {}
+            for m in modality:
+                if m == "Audio":
+                    out[m] = Compose([rt.Stack(m), rt.ToTensor(is_audio=True)])
+                    continue
+                node = cfg.data.rgb if m == "RGB" else cfg.data.flow
+                if mode == "train":
+                    sc = [1, 0.875, 0.75, 0.66] if m == "RGB" else [1, 0.875, 0.75]
+                    geo = [rt.MultiScaleCrop(cfg.data.train_crop_size, sc), rt.RandomHorizontalFlip(prob=0.5)]
+                else:
+                    geo = [rt.Rescale(cfg.data.test_scale_size), rt.CenterCrop(cfg.data.test_crop_size)]
+                out[m] = Compose(geo + [rt.Stack(m), rt.ToTensor(), rt.Normalize(node.mean, node.std)])
+            return out
+    ov = ["data.train_crop_size=32", "data.test_scale_size=40", "data.test_crop_size=32"]
+    cfg = load_config(ov)
+    rng = np.random.RandomState(21)
+    out = {}
+    meta = {"overrides": ov, "cases": []}
+    k = 0
+    for mode in ("train", "test"):
+        tf = get_transforms(cfg, ["RGB", "Flow"], mode)
+        for (h, w) in ((48, 64), (57, 45), (32, 32)):
+            for m in ("RGB", "Flow"):
+                for rep in range(2 if mode == "train" else 1):
+                    n_img = 2 if m == "RGB" else 10
+                    frames = [rng.randint(0, 256, (h, w, 3) if m == "RGB" else (h, w)).astype(np.uint8) for _ in range(n_img)]
+                    seed = 1000 + k
+                    np.random.seed(seed)
+                    res = tf[m]([f.copy() for f in frames])
+                    out["in%d" % k] = np.stack(frames, 0)
+                    out["out%d" % k] = res.numpy()
+                    meta["cases"].append({"mode": mode, "modality": m, "seed": seed, "shape": list(res.shape)})
+                    k += 1
+    np.savez_compressed(os.path.join(HERE, "transform.npz"), **out)
+    with open(os.path.join(HERE, "transform.json"), "w") as f:
+        json.dump(meta, f)
+    print("transform.npz", k, "cases")
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
-    trainstep()
-    metric()
-    scores()
-    priors()
+    which = sys.argv[1:] or ["trainstep", "metric", "scores", "priors", "transforms"]
+    for name in which:
+        globals()[name]()
