@@ -10,6 +10,8 @@ LIB = os.path.join(HERE, "libtbn_hip.so")
 SOURCES = ["api.hip", "conv_igemm.hip", "bn.hip", "pool.hip", "heads.hip", "stft.hip", "engine.hip", "train_ops.hip", "frames.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
          "-I" + os.path.join(os.path.dirname(HERE), "include")]
+if os.environ.get("TBN_DIAG") == "1":         # timing-diagnostic build (engine can skip kernel groups; results invalid)
+    FLAGS.append("-DTBN_DIAG=1")
 if os.environ.get("TBN_ABLATE") == "1":      # timing-ablation build for scripts/conv_ablate.py (never the shipped one)
     FLAGS.append("-DTBN_ABLATE=1")
 

@@ -189,10 +189,111 @@ int tbn_launch_bn_fold(const float* gamma, const float* beta, const float* mean,
   return TBN_OK;
 }
 
+// ---------------------------------------------------------------- apply + 3x3 max pool in one pass
+// For a conv whose BN-ReLU output is consumed ONLY by a max pool (the stem: conv1 -> pool1, conv2_3x3 -> pool2):
+// z = relu(y*scale+shift) is formed in registers and pooled at once; z itself is never written (the backward
+// recomputes the ReLU mask from y anyway).  Same comparison order as maxpool_fwd_kernel on a stored z (first
+// maximum in scan order, NaN propagates), so values and arg-max are identical to the two-pass form.
+__global__ __launch_bounds__(256) void bn_apply_maxpool_kernel(const float* __restrict__ y, int N, int H, int W, int C,
+                                                               const float* __restrict__ scale,
+                                                               const float* __restrict__ shift,
+                                                               float* __restrict__ out, int out_ld,
+                                                               unsigned char* __restrict__ argmax, int OH, int OW,
+                                                               int stride, int pad) {
+  const int G = C >> 2;
+  const size_t total = (size_t)N * OH * OW * G;
+  const unsigned nb = gridDim.x, bid = blockIdx.x;   // XCD-aware order: a window row is fetched into one L2
+  const unsigned q8 = nb >> 3, r8 = nb & 7, xcd = bid & 7, idx = bid >> 3;
+  const size_t b0 = (size_t)((xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx);
+  for (size_t i = b0 * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int g = (int)(i % G);
+    size_t pix = i / G;
+    const int ox = (int)(pix % OW);
+    pix /= OW;
+    const int oy = (int)(pix % OH), n = (int)(pix / OH);
+    const int y0 = oy * stride - pad, x0 = ox * stride - pad;
+    const float4 sc = *reinterpret_cast<const float4*>(scale + g * 4);
+    const float4 sh = *reinterpret_cast<const float4*>(shift + g * 4);
+    float4 best = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    int bx = 0, by = 0, bz = 0, bw = 0;
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int s2 = 0; s2 < 3; ++s2) {
+        const int iy = y0 + r, ix = x0 + s2;
+        if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
+          const float4 v = *reinterpret_cast<const float4*>(y + ((size_t)(n * H + iy) * W + ix) * C + g * 4);
+          float4 z;
+          z.x = fmaxf(fmaf(v.x, sc.x, sh.x), 0.f);
+          z.y = fmaxf(fmaf(v.y, sc.y, sh.y), 0.f);
+          z.z = fmaxf(fmaf(v.z, sc.z, sh.z), 0.f);
+          z.w = fmaxf(fmaf(v.w, sc.w, sh.w), 0.f);
+          const int k = r * 3 + s2;
+          if (z.x > best.x || z.x != z.x) { best.x = z.x; bx = k; }
+          if (z.y > best.y || z.y != z.y) { best.y = z.y; by = k; }
+          if (z.z > best.z || z.z != z.z) { best.z = z.z; bz = k; }
+          if (z.w > best.w || z.w != z.w) { best.w = z.w; bw = k; }
+        }
+      }
+    const size_t opix = (size_t)(n * OH + oy) * OW + ox;
+    *reinterpret_cast<float4*>(out + opix * out_ld + g * 4) = best;
+    *reinterpret_cast<uint32_t*>(argmax + opix * C + g * 4) =
+        (uint32_t)bx | ((uint32_t)by << 8) | ((uint32_t)bz << 16) | ((uint32_t)bw << 24);
+  }
+}
+
+int tbn_launch_bn_apply_maxpool(const float* y, int N, int H, int W, int C, const float* scale, const float* shift,
+                                float* out, int out_ld, unsigned char* argmax, int OH, int OW, int stride, int pad,
+                                hipStream_t st) {
+  TBN_REQUIRE(C % 4 == 0 && out_ld % 4 == 0 && argmax != nullptr, "bn_apply_maxpool: bad C / pitch / argmax");
+  size_t g = ((size_t)N * OH * OW * (C / 4) + 255) / 256;
+  if (g > 8192) g = 8192;
+  hipLaunchKernelGGL(bn_apply_maxpool_kernel, dim3((unsigned)(g < 1 ? 1 : g)), dim3(256), 0, st, y, N, H, W, C, scale,
+                     shift, out, out_ld, argmax, OH, OW, stride, pad);
+  TBN_CHECK_LAUNCH("bn_apply_maxpool");
+  return TBN_OK;
+}
+
+// Gradient of a max pool's INPUT formed on the fly from the pooled gradient and the stored arg-max (the gather of
+// maxpool_bwd_kernel): used by the BN-backward kernels of a conv fused with its pool, so dz is never materialised.
+struct PoolGrad {
+  const float* dout;            // gradient of the pooled tensor (N, OH, OW, C) with pitch dout_ld
+  const unsigned char* argmax;  // (N, OH, OW, C) uint8 window index
+  int dout_ld, H, W, OH, OW, C, stride, pad;
+  FastDiv div_w, div_h;
+};
+__device__ __forceinline__ float4 pooled_grad(const PoolGrad& q, int p, int c) {
+  const uint32_t row = fdiv((uint32_t)p, q.div_w);        // n*H + iy
+  const int ix = p - (int)row * q.W;
+  const uint32_t n = fdiv(row, q.div_h);
+  const int iy = (int)row - (int)n * q.H;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int oy_hi = min(q.OH - 1, (iy + q.pad) / q.stride);
+  const int ox_hi = min(q.OW - 1, (ix + q.pad) / q.stride);
+  for (int oy = oy_hi; oy >= 0; --oy) {
+    const int r = iy - (oy * q.stride - q.pad);
+    if (r > 2) break;
+    for (int ox = ox_hi; ox >= 0; --ox) {
+      const int s = ix - (ox * q.stride - q.pad);
+      if (s > 2) break;
+      const uint32_t k = (uint32_t)(r * 3 + s);
+      const size_t opix = (size_t)((int)n * q.OH + oy) * q.OW + ox;
+      const uint32_t am = *reinterpret_cast<const uint32_t*>(q.argmax + opix * q.C + c);
+      const float4 d = *reinterpret_cast<const float4*>(q.dout + opix * q.dout_ld + c);
+      if ((am & 0xff) == k) acc.x += d.x;
+      if (((am >> 8) & 0xff) == k) acc.y += d.y;
+      if (((am >> 16) & 0xff) == k) acc.z += d.z;
+      if ((am >> 24) == k) acc.w += d.w;
+    }
+  }
+  return acc;
+}
+
 // ---------------------------------------------------------------- backward
 // g = dz * [y*scale+shift > 0];  xhat = (y-mean)*rstd;  S1 = sum g, S2 = sum g*xhat
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(CSeg3 dz, const float* __restrict__ y, int P, int C,
-                                                            int pch, const float* __restrict__ scale,
+template <bool POOLED>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(CSeg3 dz, PoolGrad pg, const float* __restrict__ y, int P,
+                                                            int C, int pch, const float* __restrict__ scale,
                                                             const float* __restrict__ shift,
                                                             const float* __restrict__ mean,
                                                             const float* __restrict__ rstd,
@@ -206,7 +307,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(CSeg3 dz, const floa
     int sg = 0;
     if (dz.n > 1 && c >= dz.s[1].col_begin) sg = 1;
     if (dz.n > 2 && c >= dz.s[2].col_begin) sg = 2;
-    const float* dzp = dz.s[sg].ptr + (c - dz.s[sg].col_begin);
+    const float* dzp = POOLED ? nullptr : dz.s[sg].ptr + (c - dz.s[sg].col_begin);
     const int dld = dz.s[sg].ld;
     const float4 sc = *reinterpret_cast<const float4*>(scale + c);
     const float4 sh = *reinterpret_cast<const float4*>(shift + c);
@@ -214,7 +315,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(CSeg3 dz, const floa
     const float4 rs4 = *reinterpret_cast<const float4*>(rstd + c);
     for (int p = p0 + rs; p < p1; p += RP) {
       const float4 v = *reinterpret_cast<const float4*>(y + (size_t)p * C + c);
-      const float4 d = *reinterpret_cast<const float4*>(dzp + (size_t)p * dld);
+      const float4 d = POOLED ? pooled_grad(pg, p, c) : *reinterpret_cast<const float4*>(dzp + (size_t)p * dld);
       const float gx = fmaf(v.x, sc.x, sh.x) > 0.f ? d.x : 0.f;
       const float gy = fmaf(v.y, sc.y, sh.y) > 0.f ? d.y : 0.f;
       const float gz = fmaf(v.z, sc.z, sh.z) > 0.f ? d.z : 0.f;
@@ -258,9 +359,38 @@ int tbn_launch_bn_bwd_reduce(const CSeg* dz, int nseg, const float* y, int P, in
   CSeg3 s3;
   TBN_REQUIRE(fill_cseg3(&s3, dz, nseg) == 0, "bn_bwd_reduce: segment pitch/offset must be x4");
   const int rp = 256 / (C / 4), pch = pick_chunk(P, rp), parts = cdiv(P, pch);
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(parts), dim3(256), 0, st, s3, y, P, C, pch, scale, shift, mean, rstd,
-                     partial);
+  PoolGrad none = {};
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, dim3(parts), dim3(256), 0, st, s3, none, y, P, C, pch, scale, shift,
+                     mean, rstd, partial);
   TBN_CHECK_LAUNCH("bn_bwd_reduce");
+  return TBN_OK;
+}
+
+static PoolGrad make_poolgrad(const float* dout, int dout_ld, const unsigned char* argmax, int H, int W, int OH, int OW,
+                              int C, int stride, int pad) {
+  PoolGrad q;
+  q.dout = dout; q.argmax = argmax; q.dout_ld = dout_ld;
+  q.H = H; q.W = W; q.OH = OH; q.OW = OW; q.C = C; q.stride = stride; q.pad = pad;
+  q.div_w = make_fastdiv((uint32_t)W);
+  q.div_h = make_fastdiv((uint32_t)H);
+  return q;
+}
+
+// BN-backward reduce / apply of a conv fused with its max pool: dz = gather(dpooled, argmax) on the fly
+int tbn_launch_bn_bwd_reduce_pooled(const float* dpooled, int dpooled_ld, const unsigned char* argmax, int N, int H,
+                                    int W, int OH, int OW, int stride, int pad, const float* y, int C,
+                                    const float* scale, const float* shift, const float* mean, const float* rstd,
+                                    float* partial, hipStream_t st) {
+  TBN_REQUIRE(C % 4 == 0 && C <= 1024 && dpooled_ld % 4 == 0, "bn_bwd_reduce_pooled: bad C / pitch");
+  TBN_REQUIRE((long)N * H * W < (1l << 31), "bn_bwd_reduce_pooled: too many pixels");
+  const int P = N * H * W;
+  CSeg3 s3 = {};
+  s3.n = 1;
+  const int rp = 256 / (C / 4), pch = pick_chunk(P, rp), parts = cdiv(P, pch);
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, dim3(parts), dim3(256), 0, st, s3,
+                     make_poolgrad(dpooled, dpooled_ld, argmax, H, W, OH, OW, C, stride, pad), y, P, C, pch, scale,
+                     shift, mean, rstd, partial);
+  TBN_CHECK_LAUNCH("bn_bwd_reduce_pooled");
   return TBN_OK;
 }
 
@@ -310,7 +440,8 @@ int tbn_launch_bn_bwd_finalize(const float* partial, int nparts, int P, int C, c
 }
 
 // y and dy may alias (the engine converts y to dy in place): no __restrict__ on them
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(CSeg3 dz, const float* y, int P, int C,
+template <bool POOLED>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(CSeg3 dz, PoolGrad pg, const float* y, int P, int C,
                                                            const float* __restrict__ scale,
                                                            const float* __restrict__ shift,
                                                            const float* __restrict__ coef, float* dy) {
@@ -321,7 +452,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(CSeg3 dz, const float
     int sg = 0;
     if (dz.n > 1 && c >= dz.s[1].col_begin) sg = 1;
     if (dz.n > 2 && c >= dz.s[2].col_begin) sg = 2;
-    const float4 d = *reinterpret_cast<const float4*>(dz.s[sg].ptr + (size_t)p * dz.s[sg].ld + (c - dz.s[sg].col_begin));
+    const float4 d = POOLED ? pooled_grad(pg, p, c)
+                            : *reinterpret_cast<const float4*>(dz.s[sg].ptr + (size_t)p * dz.s[sg].ld +
+                                                               (c - dz.s[sg].col_begin));
     const float4 v = *reinterpret_cast<const float4*>(y + (size_t)p * C + c);
     const float4 sc = *reinterpret_cast<const float4*>(scale + c);
     const float4 sh = *reinterpret_cast<const float4*>(shift + c);
@@ -341,8 +474,23 @@ int tbn_launch_bn_bwd_apply(const CSeg* dz, int nseg, const float* y, int P, int
                             const float* shift, const float* coef, float* dy, hipStream_t st) {
   CSeg3 s3;
   TBN_REQUIRE(C % 4 == 0 && nseg >= 1 && nseg <= 3 && fill_cseg3(&s3, dz, nseg) == 0, "bn_bwd_apply: bad segments");
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid((size_t)P * C / 4)), dim3(256), 0, st, s3, y, P, C, scale,
-                     shift, coef, dy);
+  PoolGrad none = {};
+  hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(ew_grid((size_t)P * C / 4)), dim3(256), 0, st, s3, none, y, P, C,
+                     scale, shift, coef, dy);
   TBN_CHECK_LAUNCH("bn_bwd_apply");
+  return TBN_OK;
+}
+
+int tbn_launch_bn_bwd_apply_pooled(const float* dpooled, int dpooled_ld, const unsigned char* argmax, int N, int H, int W,
+                                   int OH, int OW, int stride, int pad, const float* y, int C, const float* scale,
+                                   const float* shift, const float* coef, float* dy, hipStream_t st) {
+  TBN_REQUIRE(C % 4 == 0 && dpooled_ld % 4 == 0, "bn_bwd_apply_pooled: bad C / pitch");
+  const int P = N * H * W;
+  CSeg3 s3 = {};
+  s3.n = 1;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(ew_grid((size_t)P * C / 4)), dim3(256), 0, st, s3,
+                     make_poolgrad(dpooled, dpooled_ld, argmax, H, W, OH, OW, C, stride, pad), y, P, C, scale, shift,
+                     coef, dy);
+  TBN_CHECK_LAUNCH("bn_bwd_apply_pooled");
   return TBN_OK;
 }

@@ -58,6 +58,7 @@ struct Conv {
   bool stem;
   bool dgrad_accum;    // dgrad adds into d(inbuf)
   bool need_dgrad;
+  int fuse_pool = -1;  // training: index of the max pool that is the ONLY consumer of this conv's BN-ReLU output
 };
 
 struct Pool {
@@ -65,6 +66,7 @@ struct Pool {
   int inbuf, outbuf, out_choff, stride, pad;
   size_t argmax_off;   // bytes
   bool bwd_accum;
+  bool fused = false;  // training: executed inside its producer conv's BN apply / BN backward (see Conv::fuse_pool)
 };
 
 struct Op {
@@ -279,8 +281,38 @@ void build_graph(tbn_backbone_plan* P) {
       written[p.inbuf] = 1;
     }
   }
+
+  // conv -> BN -> ReLU -> max pool with no other reader of the BN output (the stem: conv1 -> pool1, conv2_3x3 -> pool2):
+  // in training the pool runs inside the BN apply and its backward inside the BN backward, so the full-resolution z
+  // and dz tensors (the largest of the network) are never written or re-read.
+  std::vector<int> readers(P->bufs.size(), 0);
+  for (auto& c : P->convs) ++readers[c.inbuf];
+  for (auto& q : P->pools) ++readers[q.inbuf];
+  for (size_t pi = 0; pi < P->pools.size(); ++pi) {
+    Pool& q = P->pools[pi];
+    if (q.kind != 1 || q.bwd_accum || readers[q.inbuf] != 1 || q.inbuf == P->out_buf) continue;
+    for (auto& c : P->convs)
+      if (c.nparts == 1 && c.dst_buf[0] == q.inbuf && c.dst_choff[0] == 0 && c.cout == P->bufs[q.inbuf].C) {
+        c.fuse_pool = (int)pi;
+        q.fused = true;
+      }
+  }
 }
 
+// Timing diagnostics only (-DTBN_DIAG=1 build, never shipped): TBN_DIAG_SKIP=<bit mask> drops kernel groups
+// (1 finalize, 2 bn_apply, 4 pools, 8 bn_bwd_reduce, 16 bn_bwd_apply) to measure what each costs the step.
+#ifndef TBN_DIAG
+#define TBN_DIAG 0
+#endif
+static inline bool diag_skip(int bit) {
+#if TBN_DIAG
+  static const int mask = getenv("TBN_DIAG_SKIP") ? atoi(getenv("TBN_DIAG_SKIP")) : 0;
+  return (mask & bit) != 0;
+#else
+  (void)bit;
+  return false;
+#endif
+}
 void plan_memory(tbn_backbone_plan* P) {
   const size_t R = P->frames;
   size_t off = 0;
@@ -544,12 +576,21 @@ int tbn_backbone_forward(const tbn_backbone_plan* P, int training, const float* 
         p.stat_partial = ws + P->partial_off;
         p.stages = c.stages;
         TBN_TRY(tbn_launch_conv(p, c.stem, c.mt, c.nt, st));
-        TBN_TRY(tbn_launch_bn_finalize(ws + P->partial_off, cdiv(p.M, 128 * c.mt), p.M, c.cout, prm->gamma + c.c_off,
+        if (!diag_skip(1)) TBN_TRY(tbn_launch_bn_finalize(ws + P->partial_off, cdiv(p.M, 128 * c.mt), p.M, c.cout, prm->gamma + c.c_off,
                                        prm->beta + c.c_off, prm->bias + c.c_off, prm->running_mean + c.c_off,
                                        prm->running_var + c.c_off,
                                        prm->momentum, prm->eps, mean + c.c_off, rstd + c.c_off, scale + c.c_off,
                                        shift + c.c_off, st));
-        TBN_TRY(tbn_launch_bn_apply(y, p.M, c.cout, scale + c.c_off, shift + c.c_off, zs, c.nparts, st));
+        if (c.fuse_pool >= 0) {
+          const Pool& q = P->pools[c.fuse_pool];
+          const Buf& ob = P->bufs[q.outbuf];
+          if (!diag_skip(2))
+            TBN_TRY(tbn_launch_bn_apply_maxpool(y, (int)R, c.outH, c.outW, c.cout, scale + c.c_off, shift + c.c_off,
+                                                ws + ob.off + q.out_choff, ob.C, (uint8_t*)workspace + q.argmax_off,
+                                                ob.H, ob.W, q.stride, q.pad, st));
+        } else if (!diag_skip(2)) {
+          TBN_TRY(tbn_launch_bn_apply(y, p.M, c.cout, scale + c.c_off, shift + c.c_off, zs, c.nparts, st));
+        }
       } else {
         p.mode = CONV_EPI_EVAL;
         p.scale = scale + c.c_off;
@@ -563,11 +604,12 @@ int tbn_backbone_forward(const tbn_backbone_plan* P, int training, const float* 
       const Pool& q = P->pools[o.idx];
       const Buf& ib = P->bufs[q.inbuf];
       const Buf& ob = P->bufs[q.outbuf];
+      if (training && q.fused) continue;  // ran inside the producer's BN apply
       if (q.kind == 0) {
-        TBN_TRY(tbn_launch_avgpool3_fwd(ws + ib.off, ib.C, ws + ob.off + q.out_choff, ob.C, R, ib.H, ib.W, ib.C, 0, st));
+        if (!diag_skip(4)) TBN_TRY(tbn_launch_avgpool3_fwd(ws + ib.off, ib.C, ws + ob.off + q.out_choff, ob.C, R, ib.H, ib.W, ib.C, 0, st));
       } else {
         uint8_t* am = training ? (uint8_t*)workspace + q.argmax_off : nullptr;
-        TBN_TRY(tbn_launch_maxpool_fwd(ws + ib.off, ib.C, ws + ob.off + q.out_choff, ob.C, am, R, ib.H, ib.W, ib.C,
+        if (!diag_skip(4)) TBN_TRY(tbn_launch_maxpool_fwd(ws + ib.off, ib.C, ws + ob.off + q.out_choff, ob.C, am, R, ib.H, ib.W, ib.C,
                                        ob.H, ob.W, q.stride, q.pad, st));
       }
     }
@@ -740,12 +782,13 @@ int tbn_backbone_backward(const tbn_backbone_plan* P, const float* dfeatures, co
       const Buf& ib = P->bufs[q.inbuf];
       const Buf& ob = P->bufs[q.outbuf];
       if (q.inbuf == 0) continue;
+      if (q.fused) continue;  // its gradient gather runs inside the producer's BN backward
       float* din = ws + ib.doff;
       if (q.kind == 0) {
-        TBN_TRY(tbn_launch_avgpool3_fwd(dptr(q.outbuf) + q.out_choff, ob.C, din, ib.C, R, ib.H, ib.W, ib.C, q.bwd_accum,
+        if (!diag_skip(4)) TBN_TRY(tbn_launch_avgpool3_fwd(dptr(q.outbuf) + q.out_choff, ob.C, din, ib.C, R, ib.H, ib.W, ib.C, q.bwd_accum,
                                         st));
       } else {
-        TBN_TRY(tbn_launch_maxpool_bwd(dptr(q.outbuf) + q.out_choff, ob.C, (const uint8_t*)workspace + q.argmax_off,
+        if (!diag_skip(4)) TBN_TRY(tbn_launch_maxpool_bwd(dptr(q.outbuf) + q.out_choff, ob.C, (const uint8_t*)workspace + q.argmax_off,
                                        din, ib.C, R, ib.H, ib.W, ib.C, ob.H, ob.W, q.stride, q.pad, q.bwd_accum, st));
       }
       continue;
@@ -763,13 +806,35 @@ int tbn_backbone_backward(const tbn_backbone_plan* P, const float* dfeatures, co
       dz[i].col_begin = col;
       col += c.couts[i];
     }
-    TBN_TRY(tbn_launch_bn_bwd_reduce(dz, c.nparts, y, M, c.cout, scale + c.c_off, shift + c.c_off, mean + c.c_off,
-                                     rstd + c.c_off, partial, st));
     const bool bn_grad = g->dgamma && g->dbeta && (g->bn_grad_layers == 2 || (g->bn_grad_layers == 1 && o.idx == 0));
-    TBN_TRY(tbn_launch_bn_bwd_finalize(partial, tbn_bn_bwd_parts(M, c.cout), M, c.cout, scale + c.c_off,
-                                       mean + c.c_off, rstd + c.c_off, coef, bn_grad ? g->dgamma + c.c_off : nullptr,
-                                       bn_grad ? g->dbeta + c.c_off : nullptr, g->dbias + c.c_off, st));
-    TBN_TRY(tbn_launch_bn_bwd_apply(dz, c.nparts, y, M, c.cout, scale + c.c_off, shift + c.c_off, coef, y, st));
+    if (c.fuse_pool >= 0) {
+      const Pool& q = P->pools[c.fuse_pool];
+      const Buf& ob = P->bufs[q.outbuf];
+      const float* dpool = dptr(q.outbuf) + q.out_choff;
+      const uint8_t* am = (const uint8_t*)workspace + q.argmax_off;
+      if (!diag_skip(8))
+        TBN_TRY(tbn_launch_bn_bwd_reduce_pooled(dpool, ob.C, am, R, c.outH, c.outW, ob.H, ob.W, q.stride, q.pad, y,
+                                                c.cout, scale + c.c_off, shift + c.c_off, mean + c.c_off,
+                                                rstd + c.c_off, partial, st));
+    } else if (!diag_skip(8)) {
+      TBN_TRY(tbn_launch_bn_bwd_reduce(dz, c.nparts, y, M, c.cout, scale + c.c_off, shift + c.c_off, mean + c.c_off,
+                                       rstd + c.c_off, partial, st));
+    }
+    if (!diag_skip(1))
+      TBN_TRY(tbn_launch_bn_bwd_finalize(partial, tbn_bn_bwd_parts(M, c.cout), M, c.cout, scale + c.c_off,
+                                         mean + c.c_off, rstd + c.c_off, coef, bn_grad ? g->dgamma + c.c_off : nullptr,
+                                         bn_grad ? g->dbeta + c.c_off : nullptr, g->dbias + c.c_off, st));
+    if (c.fuse_pool >= 0) {
+      const Pool& q = P->pools[c.fuse_pool];
+      const Buf& ob = P->bufs[q.outbuf];
+      if (!diag_skip(16))
+        TBN_TRY(tbn_launch_bn_bwd_apply_pooled(dptr(q.outbuf) + q.out_choff, ob.C,
+                                               (const uint8_t*)workspace + q.argmax_off, R, c.outH, c.outW, ob.H, ob.W,
+                                               q.stride, q.pad, y, c.cout, scale + c.c_off, shift + c.c_off, coef, y,
+                                               st));
+    } else if (!diag_skip(16)) {
+      TBN_TRY(tbn_launch_bn_bwd_apply(dz, c.nparts, y, M, c.cout, scale + c.c_off, shift + c.c_off, coef, y, st));
+    }
     // weight gradient -- on the aux stream when given: it only reads dy (final after bn_bwd_apply) and
     // the layer input, so it overlaps the data-gradient / BN-backward chain that continues on `st`
     tbn_prof_label(("wgrad " + c.names[c.nparts - 1]).c_str());

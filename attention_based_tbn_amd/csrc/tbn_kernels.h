@@ -89,6 +89,16 @@ int tbn_launch_bn_finalize(const float* partial, int nparts, int P, int C, const
                            float* save_mean, float* save_rstd, float* scale, float* shift, hipStream_t st);
 int tbn_launch_bn_apply(const float* y, int P, int C, const float* scale, const float* shift, const Seg* segs,
                         int nseg, hipStream_t st);
+int tbn_launch_bn_apply_maxpool(const float* y, int N, int H, int W, int C, const float* scale, const float* shift,
+                                float* out, int out_ld, unsigned char* argmax, int OH, int OW, int stride, int pad,
+                                hipStream_t st);
+int tbn_launch_bn_bwd_reduce_pooled(const float* dpooled, int dpooled_ld, const unsigned char* argmax, int N, int H,
+                                    int W, int OH, int OW, int stride, int pad, const float* y, int C,
+                                    const float* scale, const float* shift, const float* mean, const float* rstd,
+                                    float* partial, hipStream_t st);
+int tbn_launch_bn_bwd_apply_pooled(const float* dpooled, int dpooled_ld, const unsigned char* argmax, int N, int H, int W,
+                                   int OH, int OW, int stride, int pad, const float* y, int C, const float* scale,
+                                   const float* shift, const float* coef, float* dy, hipStream_t st);
 int tbn_launch_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var, const float* bias,
                        float eps, float* scale, float* shift, int C, hipStream_t st);
 int tbn_bn_bwd_parts(int P, int C);
