@@ -59,6 +59,8 @@ struct Conv {
   bool dgrad_accum;    // dgrad adds into d(inbuf)
   bool need_dgrad;
   int fuse_pool = -1;  // training: index of the max pool that is the ONLY consumer of this conv's BN-ReLU output
+  bool post_pool = false;  // 3x3 average pool between this 1x1 conv and its BN (see build_graph, pool_proj)
+  size_t y2_off = 0;       // post_pool: pooled conv output = BN input (y_off holds the un-pooled conv output)
 };
 
 struct Pool {
@@ -252,9 +254,19 @@ void build_graph(tbn_backbone_plan* P) {
     }
     if (B.pool == 2) {
       add_pool(P, 1, x, O, B.c1 + B.c3 + B.cd2, 2, 0);
+    } else if (B.pool == 0) {
+      // reference: pool_proj(avg_pool3x3(x)).  A 3x3 / stride 1 / count_include_pad average and a (bias-free) 1x1
+      // conv commute exactly, so the conv runs on the block input and the POOLING runs on its 32..128 output
+      // channels instead of the 192..1056 input channels: 5-8x fewer bytes through the HBM-bound pool kernels
+      // (forward and backward), no pooled copy of the block input.  The bias is added after the pool (it is folded
+      // into the BN statistics / shift like everywhere else), which is where the reference adds it.
+      std::string n = pre + "_pool_proj";
+      int co = B.cp, db = O, dc = B.c1 + B.c3 + B.cd2;
+      const int ci = add_conv(P, 1, &n, &co, B.cin, 1, 1, 0, x, &db, &dc, false);
+      P->convs[ci].post_pool = true;
     } else {
       const int XP = add_buf(P, h, w, B.cin);
-      add_pool(P, B.pool == 0 ? 0 : 1, x, XP, 0, 1, 1);
+      add_pool(P, 1, x, XP, 0, 1, 1);
       std::string n = pre + "_pool_proj";
       int co = B.cp, db = O, dc = B.c1 + B.c3 + B.cd2;
       add_conv(P, 1, &n, &co, B.cin, 1, 1, 0, XP, &db, &dc, false);
@@ -360,9 +372,15 @@ void plan_memory(tbn_backbone_plan* P) {
   P->wt_floats = wtf;
   P->partial_off = take(partial);
   P->wpack_off = take((size_t)64 * 7 * P->kw);
+  for (auto& c : P->convs)   // conv output / pooled conv output of the pool-after-conv layers: needed in eval too
+    if (c.post_pool) {
+      c.y_off = take(R * c.outH * c.outW * c.cout);
+      c.y2_off = take(R * c.outH * c.outW * c.cout);
+    }
   P->eval_floats = off;
   // training-only regions
-  for (auto& c : P->convs) c.y_off = take(R * c.outH * c.outW * c.cout);
+  for (auto& c : P->convs)
+    if (!c.post_pool) c.y_off = take(R * c.outH * c.outW * c.cout);
   for (size_t i = 1; i < P->bufs.size(); ++i) {
     if ((int)i == P->out_buf) continue;  // gradient of the final feature map is supplied by the caller
     P->bufs[i].doff = take(R * P->bufs[i].H * P->bufs[i].W * P->bufs[i].C);
@@ -465,7 +483,7 @@ int tbn_backbone_tensor_info(const tbn_backbone_plan* P, const char* conv_name, 
         *rows = P->frames * c.outH * c.outW;
         *cols = c.couts[i];
         if (kind == 1) {
-          *offset = (long)(c.y_off + col);
+          *offset = (long)((c.post_pool ? c.y2_off : c.y_off) + col);
           *ld = c.cout;
         } else if (kind == 0) {
           *offset = (long)(db.off + c.dst_choff[i]);
@@ -566,7 +584,31 @@ int tbn_backbone_forward(const tbn_backbone_plan* P, int training, const float* 
         col += c.couts[i];
       }
       tbn_prof_label(("fwd " + c.names[c.nparts - 1]).c_str());
-      if (training) {
+      if (c.post_pool) {
+        // bias-free 1x1 conv on the block input -> 3x3 average of its few output channels -> BN (+ReLU) -> concat
+        float* u_raw = ws + c.y_off;
+        float* yp = ws + c.y2_off;
+        p.mode = CONV_EPI_PLAIN;
+        p.nseg = 1;
+        p.seg[0].ptr = u_raw;
+        p.seg[0].ld = c.cout;
+        p.seg[0].col_begin = 0;
+        p.stages = c.stages;
+        TBN_TRY(tbn_launch_conv(p, false, c.mt, c.nt, st));
+        if (!diag_skip(4))
+          TBN_TRY(tbn_launch_avgpool3_fwd(u_raw, c.cout, yp, c.cout, R, c.outH, c.outW, c.cout, 0, st));
+        if (training) {
+          int nparts = 0;
+          TBN_TRY(tbn_launch_bn_stats(yp, c.cout, p.M, c.cout, ws + P->partial_off, &nparts, st));
+          if (!diag_skip(1))
+            TBN_TRY(tbn_launch_bn_finalize(ws + P->partial_off, nparts, p.M, c.cout, prm->gamma + c.c_off,
+                                           prm->beta + c.c_off, prm->bias + c.c_off, prm->running_mean + c.c_off,
+                                           prm->running_var + c.c_off, prm->momentum, prm->eps, mean + c.c_off,
+                                           rstd + c.c_off, scale + c.c_off, shift + c.c_off, st));
+        }
+        if (!diag_skip(2))   // eval: scale / shift are the folded running statistics (conv bias included)
+          TBN_TRY(tbn_launch_bn_apply(yp, p.M, c.cout, scale + c.c_off, shift + c.c_off, zs, c.nparts, st));
+      } else if (training) {
         float* y = ws + c.y_off;
         p.mode = CONV_EPI_STATS;
         p.nseg = 1;
@@ -796,7 +838,8 @@ int tbn_backbone_backward(const tbn_backbone_plan* P, const float* dfeatures, co
     const Conv& c = P->convs[o.idx];
     const Buf& ib = P->bufs[c.inbuf];
     const int M = R * c.outH * c.outW;
-    float* y = ws + c.y_off;  // becomes dy in place
+    float* const dconv = ws + c.y_off;                         // gradient of the conv output, read by wgrad / dgrad
+    float* y = c.post_pool ? ws + c.y2_off : dconv;             // BN input; becomes dy in place
     CSeg dz[3];
     int col = 0;
     for (int i = 0; i < c.nparts; ++i) {
@@ -835,6 +878,8 @@ int tbn_backbone_backward(const tbn_backbone_plan* P, const float* dfeatures, co
     } else if (!diag_skip(16)) {
       TBN_TRY(tbn_launch_bn_bwd_apply(dz, c.nparts, y, M, c.cout, scale + c.c_off, shift + c.c_off, coef, y, st));
     }
+    if (c.post_pool && !diag_skip(4))   // the 3x3 average is self-adjoint: d(conv output) = avg_pool(d(pooled))
+      TBN_TRY(tbn_launch_avgpool3_fwd(y, c.cout, dconv, c.cout, R, c.outH, c.outW, c.cout, 0, st));
     // weight gradient -- on the aux stream when given: it only reads dy (final after bn_bwd_apply) and
     // the layer input, so it overlaps the data-gradient / BN-backward chain that continues on `st`
     tbn_prof_label(("wgrad " + c.names[c.nparts - 1]).c_str());
@@ -849,7 +894,7 @@ int tbn_backbone_backward(const tbn_backbone_plan* P, const float* dfeatures, co
     {
       WgradP wp;
       memset(&wp, 0, sizeof(wp));
-      wp.dy = y;
+      wp.dy = dconv;
       wp.dy_ld = c.cout;
       wp.x = ws + ib.off;
       wp.x_ld = ib.C;
@@ -885,7 +930,7 @@ int tbn_backbone_backward(const tbn_backbone_plan* P, const float* dfeatures, co
       const float* wt = ws + P->wt_off + c.w_off;
       ConvP p;
       memset(&p, 0, sizeof(p));
-      p.in = y;
+      p.in = dconv;
       p.in_ld = c.cout;
       p.wt = wt;
       p.N = R;
