@@ -7,7 +7,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libtbn_hip.so")
-SOURCES = ["api.hip", "conv_igemm.hip", "bn.hip", "pool.hip", "heads.hip", "stft.hip", "engine.hip", "train_ops.hip", "frames.hip"]
+SOURCES = ["api.hip", "conv_igemm.hip", "bn.hip", "bn_multi.hip", "pool.hip", "heads.hip", "stft.hip", "engine.hip", "train_ops.hip", "frames.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
          "-I" + os.path.join(os.path.dirname(HERE), "include")]
 if os.environ.get("TBN_DIAG") == "1":         # timing-diagnostic build (engine can skip kernel groups; results invalid)

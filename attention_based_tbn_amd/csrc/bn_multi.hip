@@ -1,0 +1,255 @@
+// Batched ("multi-tensor") training-BN kernels: the BN steps of up to three INDEPENDENT conv layers in one launch.
+//
+// Inside an inception block the 3x3, double_3x3_1 and pool_proj convs only depend on the fused 1x1 group, so
+// their BN finalize / apply (forward) and BN-backward reduce / finalize / apply form three identical little
+// kernel chains.  On this GPU every kernel on a stream's dependency chain costs ~9 us of step time no matter how
+// short it runs (measured, DESIGN.md finding 6), and a third of the ~1000 BN launches of a step belong to such
+// triples.  These kernels take up to three layer descriptors as kernel arguments; a workgroup finds its layer
+// with a scalar scan of the block-offset table and then runs the single-layer code of bn.hip on it (same
+// arithmetic, same summation order: results are bit-identical to the per-layer launches).
+#include "tbn_common.h"
+#include "tbn_kernels.h"
+
+namespace {
+
+__device__ __forceinline__ int find_layer(const int* blk0, int n, int b) {
+  int l = 0;
+  while (l + 1 < n && b >= blk0[l + 1]) ++l;
+  return l;
+}
+
+inline int ew_grid(size_t items) {
+  size_t g = (items + 255) / 256;
+  return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g));
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------- forward: finalize
+__global__ __launch_bounds__(256) void bn_finalize_multi_kernel(BnFwdBatch b) {
+  __shared__ double red[2][32][8];
+  const int li = find_layer(b.fin_blk0, b.n, blockIdx.x);
+  const BnFwdLayer& L = b.l[li];
+  const int blk = blockIdx.x - b.fin_blk0[li];
+  const int C = L.C, P = L.P;
+  const int tid = threadIdx.x, cl = tid & 7, slot = tid >> 3;
+  const int c = blk * 8 + cl;
+  double a = 0.0, s = 0.0;
+  if (c < C)
+    for (int i = slot; i < L.nparts; i += 32) {
+      a += (double)L.partial[((size_t)i * 2 + 0) * C + c];
+      s += (double)L.partial[((size_t)i * 2 + 1) * C + c];
+    }
+  red[0][slot][cl] = a;
+  red[1][slot][cl] = s;
+  __syncthreads();
+  if (slot == 0 && c < C) {
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = 0; k < 32; ++k) {
+      s1 += red[0][k][cl];
+      s2 += red[1][k][cl];
+    }
+    const double mean = s1 / P;
+    double var = s2 / P - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)b.eps));
+    const float sc = L.gamma[c] * rstd;
+    L.save_mean[c] = (float)mean;
+    L.save_rstd[c] = rstd;
+    L.scale[c] = sc;
+    L.shift[c] = fmaf(-(float)mean, sc, L.beta[c]);
+    if (L.running_mean != nullptr) {
+      const double unb = P > 1 ? var * ((double)P / (double)(P - 1)) : var;
+      const float mean_b = (float)mean + (L.conv_bias != nullptr ? L.conv_bias[c] : 0.f);
+      L.running_mean[c] = (1.f - b.momentum) * L.running_mean[c] + b.momentum * mean_b;
+      L.running_var[c] = (1.f - b.momentum) * L.running_var[c] + b.momentum * (float)unb;
+    }
+  }
+}
+
+// ---------------------------------------------------------------- forward: apply z = relu(y*scale+shift)
+__global__ __launch_bounds__(256) void bn_apply_multi_kernel(BnFwdBatch b) {
+  const int li = find_layer(b.app_blk0, b.n, blockIdx.x);
+  const BnFwdLayer& L = b.l[li];
+  const int blk = blockIdx.x - b.app_blk0[li], grid = b.app_blk0[li + 1] - b.app_blk0[li];
+  const int C = L.C, G = C >> 2;
+  const size_t total = (size_t)L.P * G;
+  const float* y = L.y;
+  for (size_t i = (size_t)blk * 256 + threadIdx.x; i < total; i += (size_t)grid * 256) {
+    const int p = (int)(i / G), c = (int)(i - (size_t)p * G) * 4;
+    const float4 v = *reinterpret_cast<const float4*>(y + (size_t)p * C + c);
+    const float4 sc = *reinterpret_cast<const float4*>(L.scale + c);
+    const float4 sh = *reinterpret_cast<const float4*>(L.shift + c);
+    float4 z;
+    z.x = fmaxf(fmaf(v.x, sc.x, sh.x), 0.f);
+    z.y = fmaxf(fmaf(v.y, sc.y, sh.y), 0.f);
+    z.z = fmaxf(fmaf(v.z, sc.z, sh.z), 0.f);
+    z.w = fmaxf(fmaf(v.w, sc.w, sh.w), 0.f);
+    int sg = 0;
+    if (L.nseg > 1 && c >= L.seg[1].col_begin) sg = 1;
+    if (L.nseg > 2 && c >= L.seg[2].col_begin) sg = 2;
+    *reinterpret_cast<float4*>(L.seg[sg].ptr + (size_t)p * L.seg[sg].ld + (c - L.seg[sg].col_begin)) = z;
+  }
+}
+
+int tbn_launch_bn_fwd_multi(BnFwdBatch& b, hipStream_t st) {
+  TBN_REQUIRE(b.n >= 1 && b.n <= TBN_BN_MAXL, "bn_fwd_multi: %d layers", b.n);
+  b.fin_blk0[0] = b.app_blk0[0] = 0;
+  for (int i = 0; i < b.n; ++i) {
+    const BnFwdLayer& L = b.l[i];
+    TBN_REQUIRE(L.C % 4 == 0 && L.nseg >= 1 && L.nseg <= 3, "bn_fwd_multi: bad C / nseg");
+    for (int s = 0; s < L.nseg; ++s)
+      TBN_REQUIRE(L.seg[s].ld % 4 == 0 && L.seg[s].col_begin % 4 == 0, "bn_fwd_multi: segment pitch/offset must be x4");
+    b.fin_blk0[i + 1] = b.fin_blk0[i] + cdiv(L.C, 8);
+    b.app_blk0[i + 1] = b.app_blk0[i] + ew_grid((size_t)L.P * L.C / 4);
+  }
+  hipLaunchKernelGGL(bn_finalize_multi_kernel, dim3(b.fin_blk0[b.n]), dim3(256), 0, st, b);
+  TBN_CHECK_LAUNCH("bn_finalize_multi");
+  hipLaunchKernelGGL(bn_apply_multi_kernel, dim3(b.app_blk0[b.n]), dim3(256), 0, st, b);
+  TBN_CHECK_LAUNCH("bn_apply_multi");
+  return TBN_OK;
+}
+
+// ---------------------------------------------------------------- backward: reduce
+// g = dz * [y*scale+shift > 0];  xhat = (y-mean)*rstd;  S1 = sum g, S2 = sum g*xhat   (per-workgroup partials)
+__global__ __launch_bounds__(256) void bn_bwd_reduce_multi_kernel(BnBwdBatch b) {
+  __shared__ float red[2 * 2048];
+  const int li = find_layer(b.red_blk0, b.n, blockIdx.x);
+  const BnBwdLayer& L = b.l[li];
+  const int blk = blockIdx.x - b.red_blk0[li];
+  const int C = L.C, P = L.P, pch = L.pch;
+  const int G = C >> 2, RP = 256 / G;
+  const int tid = threadIdx.x, cg = tid % G, rs = tid / G, c = cg * 4;
+  const int p0 = blk * pch, p1 = min(P, p0 + pch);
+  float4 s1 = make_float4(0, 0, 0, 0), s2 = s1;
+  if (rs < RP) {
+    int sg = 0;
+    if (L.nseg > 1 && c >= L.dz[1].col_begin) sg = 1;
+    if (L.nseg > 2 && c >= L.dz[2].col_begin) sg = 2;
+    const float* dzp = L.dz[sg].ptr + (c - L.dz[sg].col_begin);
+    const int dld = L.dz[sg].ld;
+    const float4 sc = *reinterpret_cast<const float4*>(L.scale + c);
+    const float4 sh = *reinterpret_cast<const float4*>(L.shift + c);
+    const float4 mu = *reinterpret_cast<const float4*>(L.mean + c);
+    const float4 rs4 = *reinterpret_cast<const float4*>(L.rstd + c);
+    const float* y = L.y;
+    for (int p = p0 + rs; p < p1; p += RP) {
+      const float4 v = *reinterpret_cast<const float4*>(y + (size_t)p * C + c);
+      const float4 d = *reinterpret_cast<const float4*>(dzp + (size_t)p * dld);
+      const float gx = fmaf(v.x, sc.x, sh.x) > 0.f ? d.x : 0.f;
+      const float gy = fmaf(v.y, sc.y, sh.y) > 0.f ? d.y : 0.f;
+      const float gz = fmaf(v.z, sc.z, sh.z) > 0.f ? d.z : 0.f;
+      const float gw = fmaf(v.w, sc.w, sh.w) > 0.f ? d.w : 0.f;
+      s1.x += gx; s1.y += gy; s1.z += gz; s1.w += gw;
+      s2.x = fmaf(gx, (v.x - mu.x) * rs4.x, s2.x);
+      s2.y = fmaf(gy, (v.y - mu.y) * rs4.y, s2.y);
+      s2.z = fmaf(gz, (v.z - mu.z) * rs4.z, s2.z);
+      s2.w = fmaf(gw, (v.w - mu.w) * rs4.w, s2.w);
+    }
+    *reinterpret_cast<float4*>(&red[(rs * G + cg) * 4]) = s1;
+    *reinterpret_cast<float4*>(&red[2048 + (rs * G + cg) * 4]) = s2;
+  }
+  __syncthreads();
+  for (int cc = tid; cc < C; cc += 256) {
+    float a = 0.f, s = 0.f;
+    for (int r = 0; r < RP; ++r) {
+      a += red[r * C + cc];
+      s += red[2048 + r * C + cc];
+    }
+    L.partial[((size_t)blk * 2 + 0) * C + cc] = a;
+    L.partial[((size_t)blk * 2 + 1) * C + cc] = s;
+  }
+}
+
+// coef[0][c]=a, coef[1][c]=b, coef[2][c]=cst with dy = a*g + b*y + cst
+__global__ __launch_bounds__(256) void bn_bwd_finalize_multi_kernel(BnBwdBatch b) {
+  __shared__ double red[2][32][8];
+  const int li = find_layer(b.fin_blk0, b.n, blockIdx.x);
+  const BnBwdLayer& L = b.l[li];
+  const int blk = blockIdx.x - b.fin_blk0[li];
+  const int C = L.C, P = L.P;
+  const int tid = threadIdx.x, cl = tid & 7, slot = tid >> 3;
+  const int c = blk * 8 + cl;
+  double a = 0.0, s = 0.0;
+  if (c < C)
+    for (int i = slot; i < L.nparts; i += 32) {
+      a += (double)L.partial[((size_t)i * 2 + 0) * C + c];
+      s += (double)L.partial[((size_t)i * 2 + 1) * C + c];
+    }
+  red[0][slot][cl] = a;
+  red[1][slot][cl] = s;
+  __syncthreads();
+  if (slot == 0 && c < C) {
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = 0; k < 32; ++k) {
+      s1 += red[0][k][cl];
+      s2 += red[1][k][cl];
+    }
+    const double sc = L.scale[c], rs = L.rstd[c], mu = L.mean[c];
+    const double bb = -sc * rs * (s2 / P);
+    L.coef[c] = (float)sc;
+    L.coef[C + c] = (float)bb;
+    L.coef[2 * C + c] = (float)(-sc * (s1 / P) - bb * mu);
+    if (L.dgamma) L.dgamma[c] = (float)s2;
+    if (L.dbeta) L.dbeta[c] = (float)s1;
+    if (L.dbias) L.dbias[c] = 0.f;   // a per-channel constant added before a batch-stat BN has exactly zero gradient
+  }
+}
+
+// y and dy alias (the engine converts y to dy in place)
+__global__ __launch_bounds__(256) void bn_bwd_apply_multi_kernel(BnBwdBatch b) {
+  const int li = find_layer(b.app_blk0, b.n, blockIdx.x);
+  const BnBwdLayer& L = b.l[li];
+  const int blk = blockIdx.x - b.app_blk0[li], grid = b.app_blk0[li + 1] - b.app_blk0[li];
+  const int C = L.C, G = C >> 2;
+  const size_t total = (size_t)L.P * G;
+  const float* y = L.y;
+  float* dy = L.dy;
+  for (size_t i = (size_t)blk * 256 + threadIdx.x; i < total; i += (size_t)grid * 256) {
+    const int p = (int)(i / G), c = (int)(i - (size_t)p * G) * 4;
+    int sg = 0;
+    if (L.nseg > 1 && c >= L.dz[1].col_begin) sg = 1;
+    if (L.nseg > 2 && c >= L.dz[2].col_begin) sg = 2;
+    const float4 d = *reinterpret_cast<const float4*>(L.dz[sg].ptr + (size_t)p * L.dz[sg].ld + (c - L.dz[sg].col_begin));
+    const float4 v = *reinterpret_cast<const float4*>(y + (size_t)p * C + c);
+    const float4 sc = *reinterpret_cast<const float4*>(L.scale + c);
+    const float4 sh = *reinterpret_cast<const float4*>(L.shift + c);
+    const float4 ca = *reinterpret_cast<const float4*>(L.coef + c);
+    const float4 cb = *reinterpret_cast<const float4*>(L.coef + C + c);
+    const float4 cc = *reinterpret_cast<const float4*>(L.coef + 2 * C + c);
+    float4 o;
+    o.x = fmaf(ca.x, fmaf(v.x, sc.x, sh.x) > 0.f ? d.x : 0.f, fmaf(cb.x, v.x, cc.x));
+    o.y = fmaf(ca.y, fmaf(v.y, sc.y, sh.y) > 0.f ? d.y : 0.f, fmaf(cb.y, v.y, cc.y));
+    o.z = fmaf(ca.z, fmaf(v.z, sc.z, sh.z) > 0.f ? d.z : 0.f, fmaf(cb.z, v.z, cc.z));
+    o.w = fmaf(ca.w, fmaf(v.w, sc.w, sh.w) > 0.f ? d.w : 0.f, fmaf(cb.w, v.w, cc.w));
+    *reinterpret_cast<float4*>(dy + (size_t)p * C + c) = o;
+  }
+}
+
+int tbn_launch_bn_bwd_multi(BnBwdBatch& b, hipStream_t st) {
+  TBN_REQUIRE(b.n >= 1 && b.n <= TBN_BN_MAXL, "bn_bwd_multi: %d layers", b.n);
+  b.red_blk0[0] = b.fin_blk0[0] = b.app_blk0[0] = 0;
+  for (int i = 0; i < b.n; ++i) {
+    BnBwdLayer& L = b.l[i];
+    TBN_REQUIRE(L.C % 4 == 0 && L.C <= 1024 && L.nseg >= 1 && L.nseg <= 3, "bn_bwd_multi: bad C / nseg");
+    for (int s = 0; s < L.nseg; ++s)
+      TBN_REQUIRE(L.dz[s].ld % 4 == 0 && L.dz[s].col_begin % 4 == 0, "bn_bwd_multi: segment pitch/offset must be x4");
+    {  // same chunking as bn.hip's single-layer launch: rows per workgroup rounded to the row-lane count
+      const int rp = 256 / (L.C / 4);
+      int pch = cdiv(L.P, 512);
+      if (pch < 64) pch = 64;
+      L.pch = cdiv(pch, rp) * rp;
+      L.nparts = cdiv(L.P, L.pch);
+    }
+    b.red_blk0[i + 1] = b.red_blk0[i] + L.nparts;
+    b.fin_blk0[i + 1] = b.fin_blk0[i] + cdiv(L.C, 8);
+    b.app_blk0[i + 1] = b.app_blk0[i] + ew_grid((size_t)L.P * L.C / 4);
+  }
+  hipLaunchKernelGGL(bn_bwd_reduce_multi_kernel, dim3(b.red_blk0[b.n]), dim3(256), 0, st, b);
+  TBN_CHECK_LAUNCH("bn_bwd_reduce_multi");
+  hipLaunchKernelGGL(bn_bwd_finalize_multi_kernel, dim3(b.fin_blk0[b.n]), dim3(256), 0, st, b);
+  TBN_CHECK_LAUNCH("bn_bwd_finalize_multi");
+  hipLaunchKernelGGL(bn_bwd_apply_multi_kernel, dim3(b.app_blk0[b.n]), dim3(256), 0, st, b);
+  TBN_CHECK_LAUNCH("bn_bwd_apply_multi");
+  return TBN_OK;
+}

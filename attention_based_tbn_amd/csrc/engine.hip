@@ -59,6 +59,7 @@ struct Conv {
   bool dgrad_accum;    // dgrad adds into d(inbuf)
   bool need_dgrad;
   int fuse_pool = -1;  // training: index of the max pool that is the ONLY consumer of this conv's BN-ReLU output
+  int group = -1, group_pos = 0, group_size = 1;  // training: BN kernels batched with the other members (bn_multi.hip)
   bool post_pool = false;  // 3x3 average pool between this 1x1 conv and its BN (see build_graph, pool_proj)
   size_t y2_off = 0;       // post_pool: pooled conv output = BN input (y_off holds the un-pooled conv output)
 };
@@ -214,6 +215,7 @@ void build_graph(tbn_backbone_plan* P) {
     const int T1 = add_buf(P, h, w, B.c3r);
     const int T2 = add_buf(P, h, w, B.cdr);
     const int T3 = add_buf(P, h, w, B.cd1);
+    int pool_in = x;
     // fused 1x1 group on the block input
     {
       std::string names[3];
@@ -237,20 +239,23 @@ void build_graph(tbn_backbone_plan* P) {
       ++n;
       add_conv(P, n, names, couts, B.cin, 1, 1, 0, x, db, dc, false);
     }
+    // The 3x3, double_3x3_1 and pool_proj convs only depend on the fused 1x1 group: they are issued back to back
+    // and share ONE batched BN finalize / apply (forward) and BN-backward reduce / finalize / apply launch set.
+    int members[3], nm = 0;
+    if (B.pool == 1) {   // 5b: 3x3 / stride-1 max pool of the block input feeds pool_proj (not linear: stays in front)
+      const int XP = add_buf(P, h, w, B.cin);
+      add_pool(P, 1, x, XP, 0, 1, 1);
+      pool_in = XP;
+    }
     {
       std::string n = pre + "_3x3";
       int co = B.c3, db = O, dc = B.c1;
-      add_conv(P, 1, &n, &co, B.c3r, 3, B.stride, 1, T1, &db, &dc, false);
+      members[nm++] = add_conv(P, 1, &n, &co, B.c3r, 3, B.stride, 1, T1, &db, &dc, false);
     }
     {
       std::string n = pre + "_double_3x3_1";
       int co = B.cd1, db = T3, dc = 0;
-      add_conv(P, 1, &n, &co, B.cdr, 3, 1, 1, T2, &db, &dc, false);
-    }
-    {
-      std::string n = pre + "_double_3x3_2";
-      int co = B.cd2, db = O, dc = B.c1 + B.c3;
-      add_conv(P, 1, &n, &co, B.cd1, 3, B.stride, 1, T3, &db, &dc, false);
+      members[nm++] = add_conv(P, 1, &n, &co, B.cdr, 3, 1, 1, T2, &db, &dc, false);
     }
     if (B.pool == 2) {
       add_pool(P, 1, x, O, B.c1 + B.c3 + B.cd2, 2, 0);
@@ -264,12 +269,22 @@ void build_graph(tbn_backbone_plan* P) {
       int co = B.cp, db = O, dc = B.c1 + B.c3 + B.cd2;
       const int ci = add_conv(P, 1, &n, &co, B.cin, 1, 1, 0, x, &db, &dc, false);
       P->convs[ci].post_pool = true;
+      members[nm++] = ci;
     } else {
-      const int XP = add_buf(P, h, w, B.cin);
-      add_pool(P, 1, x, XP, 0, 1, 1);
       std::string n = pre + "_pool_proj";
       int co = B.cp, db = O, dc = B.c1 + B.c3 + B.cd2;
-      add_conv(P, 1, &n, &co, B.cin, 1, 1, 0, XP, &db, &dc, false);
+      members[nm++] = add_conv(P, 1, &n, &co, B.cin, 1, 1, 0, pool_in, &db, &dc, false);
+    }
+    for (int k = 0; k < nm; ++k) {
+      Conv& c = P->convs[members[k]];
+      c.group = bi;
+      c.group_pos = k;
+      c.group_size = nm;
+    }
+    {
+      std::string n = pre + "_double_3x3_2";
+      int co = B.cd2, db = O, dc = B.c1 + B.c3;
+      add_conv(P, 1, &n, &co, B.cd1, 3, B.stride, 1, T3, &db, &dc, false);
     }
     x = O;
     h = oh;
@@ -370,7 +385,7 @@ void plan_memory(tbn_backbone_plan* P) {
   P->partial_floats = partial;
   P->wsplit_floats = wsplit;
   P->wt_floats = wtf;
-  P->partial_off = take(partial);
+  P->partial_off = take(TBN_BN_MAXL * partial);   // one region per member of a batched BN group
   P->wpack_off = take((size_t)64 * 7 * P->kw);
   for (auto& c : P->convs)   // conv output / pooled conv output of the pool-after-conv layers: needed in eval too
     if (c.post_pool) {
@@ -385,7 +400,7 @@ void plan_memory(tbn_backbone_plan* P) {
     if ((int)i == P->out_buf) continue;  // gradient of the final feature map is supplied by the caller
     P->bufs[i].doff = take(R * P->bufs[i].H * P->bufs[i].W * P->bufs[i].C);
   }
-  P->coef_off = take(3 * 1024);
+  P->coef_off = take(TBN_BN_MAXL * 3 * 1024);
   P->wsplit_off = take(wsplit);
   P->wt_off = take(wtf);
   P->dwpack_off = take((size_t)64 * 7 * P->kw);
@@ -541,6 +556,8 @@ int tbn_backbone_forward(const tbn_backbone_plan* P, int training, const float* 
     TBN_TRY(tbn_launch_bn_fold(prm->gamma, prm->beta, prm->running_mean, prm->running_var, prm->bias, prm->eps, scale,
                                shift, (int)P->chan_floats, st));
 
+  BnFwdBatch fwd_batch;
+  memset(&fwd_batch, 0, sizeof(fwd_batch));
   for (const Op& o : P->ops) {
     if (o.kind == 0) {
       const Conv& c = P->convs[o.idx];
@@ -584,10 +601,15 @@ int tbn_backbone_forward(const tbn_backbone_plan* P, int training, const float* 
         col += c.couts[i];
       }
       tbn_prof_label(("fwd " + c.names[c.nparts - 1]).c_str());
+      // members of a batched BN group (training) write their statistics partials into their own scratch region
+      const bool grouped = training && c.group >= 0;
+      float* part = ws + P->partial_off + (grouped ? (size_t)c.group_pos * P->partial_floats : 0);
+      float* bn_in = ws + c.y_off;     // BN input (post_pool: the pooled conv output)
+      int nparts = 0;
       if (c.post_pool) {
         // bias-free 1x1 conv on the block input -> 3x3 average of its few output channels -> BN (+ReLU) -> concat
         float* u_raw = ws + c.y_off;
-        float* yp = ws + c.y2_off;
+        bn_in = ws + c.y2_off;
         p.mode = CONV_EPI_PLAIN;
         p.nseg = 1;
         p.seg[0].ptr = u_raw;
@@ -596,43 +618,62 @@ int tbn_backbone_forward(const tbn_backbone_plan* P, int training, const float* 
         p.stages = c.stages;
         TBN_TRY(tbn_launch_conv(p, false, c.mt, c.nt, st));
         if (!diag_skip(4))
-          TBN_TRY(tbn_launch_avgpool3_fwd(u_raw, c.cout, yp, c.cout, R, c.outH, c.outW, c.cout, 0, st));
-        if (training) {
-          int nparts = 0;
-          TBN_TRY(tbn_launch_bn_stats(yp, c.cout, p.M, c.cout, ws + P->partial_off, &nparts, st));
-          if (!diag_skip(1))
-            TBN_TRY(tbn_launch_bn_finalize(ws + P->partial_off, nparts, p.M, c.cout, prm->gamma + c.c_off,
-                                           prm->beta + c.c_off, prm->bias + c.c_off, prm->running_mean + c.c_off,
-                                           prm->running_var + c.c_off, prm->momentum, prm->eps, mean + c.c_off,
-                                           rstd + c.c_off, scale + c.c_off, shift + c.c_off, st));
-        }
-        if (!diag_skip(2))   // eval: scale / shift are the folded running statistics (conv bias included)
-          TBN_TRY(tbn_launch_bn_apply(yp, p.M, c.cout, scale + c.c_off, shift + c.c_off, zs, c.nparts, st));
+          TBN_TRY(tbn_launch_avgpool3_fwd(u_raw, c.cout, bn_in, c.cout, R, c.outH, c.outW, c.cout, 0, st));
+        if (training) TBN_TRY(tbn_launch_bn_stats(bn_in, c.cout, p.M, c.cout, part, &nparts, st));
       } else if (training) {
-        float* y = ws + c.y_off;
         p.mode = CONV_EPI_STATS;
         p.nseg = 1;
-        p.seg[0].ptr = y;
+        p.seg[0].ptr = bn_in;
         p.seg[0].ld = c.cout;
         p.seg[0].col_begin = 0;
-        p.stat_partial = ws + P->partial_off;
+        p.stat_partial = part;
         p.stages = c.stages;
         TBN_TRY(tbn_launch_conv(p, c.stem, c.mt, c.nt, st));
-        if (!diag_skip(1)) TBN_TRY(tbn_launch_bn_finalize(ws + P->partial_off, cdiv(p.M, 128 * c.mt), p.M, c.cout, prm->gamma + c.c_off,
-                                       prm->beta + c.c_off, prm->bias + c.c_off, prm->running_mean + c.c_off,
-                                       prm->running_var + c.c_off,
-                                       prm->momentum, prm->eps, mean + c.c_off, rstd + c.c_off, scale + c.c_off,
-                                       shift + c.c_off, st));
+        nparts = cdiv(p.M, 128 * c.mt);
+      }
+      if (grouped) {
+        BnFwdLayer& L = fwd_batch.l[c.group_pos];
+        L.y = bn_in;
+        L.P = p.M;
+        L.C = c.cout;
+        L.partial = part;
+        L.nparts = nparts;
+        L.gamma = prm->gamma + c.c_off;
+        L.beta = prm->beta + c.c_off;
+        L.conv_bias = prm->bias + c.c_off;
+        L.running_mean = prm->running_mean + c.c_off;
+        L.running_var = prm->running_var + c.c_off;
+        L.save_mean = mean + c.c_off;
+        L.save_rstd = rstd + c.c_off;
+        L.scale = scale + c.c_off;
+        L.shift = shift + c.c_off;
+        L.nseg = c.nparts;
+        for (int i = 0; i < c.nparts; ++i) L.seg[i] = zs[i];
+        if (c.group_pos == c.group_size - 1) {   // last member issued: one finalize + one apply for the group
+          fwd_batch.n = c.group_size;
+          fwd_batch.momentum = prm->momentum;
+          fwd_batch.eps = prm->eps;
+          if (!diag_skip(3)) TBN_TRY(tbn_launch_bn_fwd_multi(fwd_batch, st));
+        }
+      } else if (training) {
+        if (!diag_skip(1))
+          TBN_TRY(tbn_launch_bn_finalize(part, nparts, p.M, c.cout, prm->gamma + c.c_off, prm->beta + c.c_off,
+                                         prm->bias + c.c_off, prm->running_mean + c.c_off, prm->running_var + c.c_off,
+                                         prm->momentum, prm->eps, mean + c.c_off, rstd + c.c_off, scale + c.c_off,
+                                         shift + c.c_off, st));
         if (c.fuse_pool >= 0) {
           const Pool& q = P->pools[c.fuse_pool];
           const Buf& ob = P->bufs[q.outbuf];
           if (!diag_skip(2))
-            TBN_TRY(tbn_launch_bn_apply_maxpool(y, (int)R, c.outH, c.outW, c.cout, scale + c.c_off, shift + c.c_off,
+            TBN_TRY(tbn_launch_bn_apply_maxpool(bn_in, (int)R, c.outH, c.outW, c.cout, scale + c.c_off, shift + c.c_off,
                                                 ws + ob.off + q.out_choff, ob.C, (uint8_t*)workspace + q.argmax_off,
                                                 ob.H, ob.W, q.stride, q.pad, st));
         } else if (!diag_skip(2)) {
-          TBN_TRY(tbn_launch_bn_apply(y, p.M, c.cout, scale + c.c_off, shift + c.c_off, zs, c.nparts, st));
+          TBN_TRY(tbn_launch_bn_apply(bn_in, p.M, c.cout, scale + c.c_off, shift + c.c_off, zs, c.nparts, st));
         }
+      } else if (c.post_pool) {
+        if (!diag_skip(2))   // eval: scale / shift are the folded running statistics (conv bias included)
+          TBN_TRY(tbn_launch_bn_apply(bn_in, p.M, c.cout, scale + c.c_off, shift + c.c_off, zs, c.nparts, st));
       } else {
         p.mode = CONV_EPI_EVAL;
         p.scale = scale + c.c_off;
@@ -850,6 +891,42 @@ int tbn_backbone_backward(const tbn_backbone_plan* P, const float* dfeatures, co
       col += c.couts[i];
     }
     const bool bn_grad = g->dgamma && g->dbeta && (g->bn_grad_layers == 2 || (g->bn_grad_layers == 1 && o.idx == 0));
+    if (c.group >= 0) {
+      // batched BN backward of the whole group, issued when the reverse walk reaches its LAST member: the gradients
+      // wrt every member's BN output exist by then (concat gradient, or the data gradient of double_3x3_2)
+      if (c.group_pos == c.group_size - 1) {
+        BnBwdBatch bb;
+        memset(&bb, 0, sizeof(bb));
+        bb.n = c.group_size;
+        for (int k = 0; k < c.group_size; ++k) {
+          const Conv& m = P->convs[o.idx - (c.group_size - 1 - k)];   // members are consecutive convs
+          BnBwdLayer& L = bb.l[m.group_pos];
+          int mc = 0;
+          for (int i = 0; i < m.nparts; ++i) {
+            const Buf& db = P->bufs[m.dst_buf[i]];
+            L.dz[i].ptr = dptr(m.dst_buf[i]) + m.dst_choff[i];
+            L.dz[i].ld = db.C;
+            L.dz[i].col_begin = mc;
+            mc += m.couts[i];
+          }
+          L.nseg = m.nparts;
+          L.y = L.dy = m.post_pool ? ws + m.y2_off : ws + m.y_off;
+          L.P = R * m.outH * m.outW;
+          L.C = m.cout;
+          L.scale = scale + m.c_off;
+          L.shift = shift + m.c_off;
+          L.mean = mean + m.c_off;
+          L.rstd = rstd + m.c_off;
+          L.partial = partial + (size_t)m.group_pos * P->partial_floats;
+          L.coef = coef + (size_t)m.group_pos * 3 * 1024;
+          const bool mg = g->dgamma && g->dbeta && g->bn_grad_layers == 2;   // members are never the first layer
+          L.dgamma = mg ? g->dgamma + m.c_off : nullptr;
+          L.dbeta = mg ? g->dbeta + m.c_off : nullptr;
+          L.dbias = g->dbias + m.c_off;
+        }
+        if (!diag_skip(27)) TBN_TRY(tbn_launch_bn_bwd_multi(bb, st));
+      }
+    } else {
     if (c.fuse_pool >= 0) {
       const Pool& q = P->pools[c.fuse_pool];
       const Buf& ob = P->bufs[q.outbuf];
@@ -877,6 +954,7 @@ int tbn_backbone_backward(const tbn_backbone_plan* P, const float* dfeatures, co
                                                st));
     } else if (!diag_skip(16)) {
       TBN_TRY(tbn_launch_bn_bwd_apply(dz, c.nparts, y, M, c.cout, scale + c.c_off, shift + c.c_off, coef, y, st));
+    }
     }
     if (c.post_pool && !diag_skip(4))   // the 3x3 average is self-adjoint: d(conv output) = avg_pool(d(pooled))
       TBN_TRY(tbn_launch_avgpool3_fwd(y, c.cout, dconv, c.cout, R, c.outH, c.outW, c.cout, 0, st));

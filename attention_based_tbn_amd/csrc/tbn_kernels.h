@@ -99,6 +99,43 @@ int tbn_launch_bn_bwd_reduce_pooled(const float* dpooled, int dpooled_ld, const 
 int tbn_launch_bn_bwd_apply_pooled(const float* dpooled, int dpooled_ld, const unsigned char* argmax, int N, int H, int W,
                                    int OH, int OW, int stride, int pad, const float* y, int C, const float* scale,
                                    const float* shift, const float* coef, float* dy, hipStream_t st);
+// batched training-BN launches over up to three independent layers (bn_multi.hip)
+#define TBN_BN_MAXL 3
+struct BnFwdLayer {
+  const float* y;           // BN input (P, C) pitch C
+  int P, C;
+  const float* partial;     // [nparts][2][C] statistics partials
+  int nparts;
+  const float *gamma, *beta, *conv_bias;
+  float *running_mean, *running_var, *save_mean, *save_rstd, *scale, *shift;
+  Seg seg[3];               // destination column ranges of z
+  int nseg;
+};
+struct BnFwdBatch {
+  int n;
+  float momentum, eps;
+  BnFwdLayer l[TBN_BN_MAXL];
+  int fin_blk0[TBN_BN_MAXL + 1], app_blk0[TBN_BN_MAXL + 1];   // filled by the launcher
+};
+struct BnBwdLayer {
+  CSeg dz[3];               // gradient wrt z, by column range
+  int nseg;
+  const float* y;           // BN input; dy is written in place
+  float* dy;
+  int P, C;
+  const float *scale, *shift, *mean, *rstd;
+  float* partial;           // scratch [nparts][2][C]
+  float* coef;              // scratch [3][C]
+  float *dgamma, *dbeta, *dbias;
+  int pch, nparts;          // filled by the launcher
+};
+struct BnBwdBatch {
+  int n;
+  BnBwdLayer l[TBN_BN_MAXL];
+  int red_blk0[TBN_BN_MAXL + 1], fin_blk0[TBN_BN_MAXL + 1], app_blk0[TBN_BN_MAXL + 1];   // filled by the launcher
+};
+int tbn_launch_bn_fwd_multi(BnFwdBatch& b, hipStream_t st);   // finalize + apply of every layer: 2 launches
+int tbn_launch_bn_bwd_multi(BnBwdBatch& b, hipStream_t st);   // reduce + finalize + apply: 3 launches
 int tbn_launch_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var, const float* bias,
                        float eps, float* scale, float* shift, int C, hipStream_t st);
 int tbn_bn_bwd_parts(int P, int C);
