@@ -26,9 +26,6 @@
 #include "tbn_common.h"
 #include "tbn_kernels.h"
 
-#ifndef TBN_WPAD
-#define TBN_WPAD 4
-#endif
 #define LDT 36  // LDS row pitch in floats (32 + 4): 16-B aligned rows, conflict-free b128 reads
 // Timing ablations of the main loop (scripts/conv_ablate.py) exist only in a -DTBN_ABLATE=1 build: as run-time
 // flags their scalar branches cut the K loop into basic blocks and cost the production kernel ~10 %.
@@ -381,7 +378,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
 // in fixed order (deterministic), then stored to `out` (final dW or a split-K slab).
 template <int MT, int NT, bool ROWMODE>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
-  constexpr int WA = 32 * MT + TBN_WPAD, WB = 32 * NT + TBN_WPAD;  // LDS pitches
+  constexpr int WA = 32 * MT + 4, WB = 32 * NT + 4;  // LDS pitches (a +16 pad removes the write conflicts but gains nothing)
   constexpr int KR = 16;                             // pixel rows per wave step
   constexpr int TILE = KR * (WA + WB);
   constexpr int LDSF = (4 * TILE > 4 * 1024 ? 4 * TILE : 4 * 1024);
