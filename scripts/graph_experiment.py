@@ -15,6 +15,11 @@ params = [p for p in model.parameters() if p.requires_grad]
 opt = FusedSGD(params, lr=cfg.train.optim.lr, momentum=cfg.train.optim.momentum, weight_decay=cfg.train.optim.weight_decay)
 B, n = 32, 3
 inp, tgt = bench.synthetic_batch(B, n, dev, 0, modality)
+core = getattr(model, "module", model)
+core.multi_stream = os.environ.get("MULTI", "1") == "1"
+for m in modality:
+    getattr(core, "Base_" + m).use_aux_stream = os.environ.get("AUX", "1") == "1"
+print("multi_stream", core.multi_stream, "aux", os.environ.get("AUX", "1"), flush=True)
 
 def step():
     opt.zero_grad(set_to_none=True)
