@@ -156,7 +156,7 @@ def reference_named_grads(model):
     return out
 
 
-@pytest.mark.parametrize("cin_hw", [(3, 64, 64), (10, 96, 64), (1, 128, 256), (3, 224, 224)])
+@pytest.mark.parametrize("cin_hw", [(3, 64, 64), (10, 96, 64), (1, 128, 256), (3, 224, 224), (3, 97, 97), (10, 70, 129)])
 def test_backbone_all_layer_grads_vs_oracle(cin_hw):
     """every conv / BN parameter gradient of one backbone + running stats, train mode.
     (audio uses H=128: with H=64 the last maps are 2 rows high, the 3x3/pad-1 average pool then
@@ -204,8 +204,13 @@ def test_backbone_all_layer_grads_vs_oracle(cin_hw):
             # (seen at inception_4d_double_3x3_1 while the layers after it sat at 2e-4).  Genuine indexing /
             # accumulation bugs showed up as >= 5e-2 on every input size and fail the cosine test too.
             floor = 4.4e-2 if H * W <= 64 * 64 else 2e-2
+            cos_min = 0.999
+            if H % 2 or W % 2:
+                # odd sizes exercise the partial ceil-mode pool windows (fused stem pools, gather backward); their
+                # 4x4 / 3x3 late maps make a single flipped decision worth up to ~5e-2, an indexing bug >> 1e-1
+                floor, cos_min = 8e-2, 0.995
             assert e_hip < max(floor, 4 * e_cpu), (key, e_hip, e_cpu)
-            assert cosine(got, truth) > 0.999, key
+            assert cosine(got, truth) > cos_min, key
     so, sn = ora.state_dict(), net.state_dict()
     for k in so:
         if "running" in k or "num_batches" in k:
