@@ -169,7 +169,9 @@ int add_pool(tbn_backbone_plan* P, int kind, int inbuf, int outbuf, int out_chof
   return o.idx;
 }
 
-void build_graph(tbn_backbone_plan* P) {
+// false: the input size makes the reference graph itself inconsistent (its torch.cat of a stride-2 conv branch and the
+// ceil-mode pass-through max pool raises)
+bool build_graph(tbn_backbone_plan* P) {
   const int cin0 = P->cin0;
   P->cp = (cin0 + 3) / 4 * 4;
   P->kw = (7 * P->cp + 31) / 32 * 32;
@@ -258,6 +260,7 @@ void build_graph(tbn_backbone_plan* P) {
       members[nm++] = add_conv(P, 1, &n, &co, B.cdr, 3, 1, 1, T2, &db, &dc, false);
     }
     if (B.pool == 2) {
+      if (pool_out(h, 3, 2, 0, true) != oh || pool_out(w, 3, 2, 0, true) != ow) return false;
       add_pool(P, 1, x, O, B.c1 + B.c3 + B.cd2, 2, 0);
     } else if (B.pool == 0) {
       // reference: pool_proj(avg_pool3x3(x)).  A 3x3 / stride 1 / count_include_pad average and a (bias-free) 1x1
@@ -324,6 +327,7 @@ void build_graph(tbn_backbone_plan* P) {
         q.fused = true;
       }
   }
+  return true;
 }
 
 // Timing diagnostics only (-DTBN_DIAG=1 build, never shipped): TBN_DIAG_SKIP=<bit mask> drops kernel groups
@@ -431,7 +435,13 @@ int tbn_backbone_plan_create(int in_channels, int frames, int height, int width,
   P->frames = frames;
   P->H = height;
   P->W = width;
-  build_graph(P);
+  if (!build_graph(P) || P->bufs[P->out_buf].H < 1 || P->bufs[P->out_buf].W < 1) {
+    delete P;
+    tbn_set_error("plan_create: %dx%d input is not a valid BN-Inception size (the stride-2 conv branches and the "
+                  "ceil-mode pass-through max pool of inception_3c / 4e disagree; the reference's torch.cat raises)",
+                  height, width);
+    return TBN_ERR_UNSUPPORTED;
+  }
   {
     int nd = 0;
     for (auto& c : P->convs) nd += c.need_dgrad ? 1 : 0;

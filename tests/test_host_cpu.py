@@ -186,3 +186,33 @@ def test_dataparallel_gradient_average_gloo_world2(tmp_path):
     outs = [p.communicate(timeout=240)[0] for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and f"DP_OK {r}" in o, o
+
+
+def test_plan_create_accepts_exactly_the_sizes_the_reference_graph_accepts():
+    """inception_3c / 4e concatenate stride-2 conv branches (floor) with a ceil-mode max pool: for some input sizes
+    the reference's torch.cat raises.  The engine plan must refuse those sizes (it would otherwise write a pooled
+    slice of the wrong extent) and accept all others.  Host-only: plan_create needs no GPU."""
+    import ctypes as C
+    import torch
+    from attention_based_tbn_amd._lib import lib
+    from oracle.bninception import BNInception as OBN
+    L = lib()
+    m = OBN(1000, 3).eval()
+    seen = set()
+    for h in range(32, 120, 11):
+        for w in (32, 57, 75, 80, 91, 112):
+            hd = C.c_void_p()
+            rc = L.tbn_backbone_plan_create(3, 1, h, w, C.byref(hd))
+            try:
+                with torch.no_grad():
+                    m.features(torch.zeros(1, 3, h, w))
+                ok = True
+            except RuntimeError:
+                ok = False
+            assert (rc == 0) == ok, (h, w, rc, ok)
+            seen.add(ok)
+            if rc == 0:
+                L.tbn_backbone_plan_destroy(hd)
+            else:
+                assert b"not a valid BN-Inception size" in L.tbn_last_error()
+    assert seen == {True, False}
