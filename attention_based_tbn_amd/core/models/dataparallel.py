@@ -3,10 +3,11 @@
 Replaces reference core/models/dataparallel.py:4-6 (single-process nn.DataParallel: per-step
 parameter broadcast + scatter/gather + reduce to GPU 0).  Here every rank holds a replica, runs
 the full forward/backward on its own shard of the clips (per-replica BatchNorm statistics, as
-nn.DataParallel's chunks had) and gradients are averaged with ONE collective per parameter
-tensor -- the backbones keep their parameters in a few flat tensors, so that is a handful of
-large all-reduces (~41 MB per backbone), issued on RCCL's stream at the end of backward (when the
-engine has joined the per-backbone side streams).  No collective on the data path.
+nn.DataParallel's chunks had) and gradients are averaged with one collective per LARGE parameter
+tensor -- the backbones keep their parameters in a few flat tensors (~41 MB per backbone) -- plus ONE
+for all small tensors (heads, biases, BN affine) packed into a flat buffer: four all-reduces per step,
+issued on RCCL's stream at the end of backward (when the engine has joined the per-backbone side
+streams).  No collective on the data path.
 
 `DataParallel(model)` keeps the reference surface: `.module`, `forward`, `get_loss(...)`,
 `state_dict()` of the wrapped model under the `module.` prefix.
@@ -53,20 +54,33 @@ class DataParallel(nn.Module):
             self._callback_queued = True
             torch.autograd.Variable._execution_engine.queue_callback(self.finish_gradient_sync)
 
+    SMALL = 1 << 18   # elements: gradients below 1 MB travel together in one flat buffer (one collective)
+
     def finish_gradient_sync(self):
-        """average every gradient produced by this backward across ranks (RCCL all-reduce)"""
+        """average every gradient produced by this backward across ranks (RCCL all-reduce): one collective per
+        large (flat backbone) tensor, ONE for all the small head / bias / BN tensors together"""
         avg = dist.get_backend(self.process_group) == "nccl"
-        works = []
-        for p in self._ready:
-            g = p.grad
-            if g is None:
-                continue
-            op = dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM
-            works.append((dist.all_reduce(g, op=op, group=self.process_group, async_op=True), None if avg else g))
-        for work, g in works:
+        op = dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM
+        grads = [p.grad for p in self._ready if p.grad is not None]
+        small = [g for g in grads if g.numel() < self.SMALL]
+        large = [g for g in grads if g.numel() >= self.SMALL]
+        works = [dist.all_reduce(g, op=op, group=self.process_group, async_op=True) for g in large]
+        flat = None
+        if small:
+            flat = torch.cat([g.reshape(-1) for g in small])
+            works.append(dist.all_reduce(flat, op=op, group=self.process_group, async_op=True))
+        for work in works:
             work.wait()          # stream-level wait on RCCL; host-blocking only on gloo
-            if g is not None:
+        if not avg:
+            for g in large:
                 g.div_(self.world_size)
+            if flat is not None:
+                flat.div_(self.world_size)
+        if flat is not None:
+            off = 0
+            for g in small:
+                g.copy_(flat[off:off + g.numel()].view_as(g))
+                off += g.numel()
         self._ready = []
         self._pending = []
         self._callback_queued = False
