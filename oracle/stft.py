@@ -59,3 +59,55 @@ def trim_audio(aud_sample, frame_idx, audio_length, sampling_rate=24000, vid_fps
     if start + min_len > max_len:
         start = max_len - min_len
     return aud_sample[start:start + min_len], start_sec
+
+
+# ---------------------------------------------------------------------------------------------------
+# spec_type "logms" (reference dataset.py:496-506): librosa.feature.melspectrogram(sample, sr, n_fft=511,
+# window="hann", hop_length, win_length, pad_mode="constant") followed by librosa.power_to_db(S, ref=np.max).
+# librosa 0.7.2's published algorithm, restated (PARITY UNPINNED, librosa is not installable offline):
+#   S = |stft|^2 (power = 2.0);  mel basis = librosa.filters.mel(sr, n_fft, n_mels=128, fmin=0, fmax=sr/2,
+#   htk=False, norm=1 "slaney"): Slaney mel scale (linear below 1 kHz, log above), triangular filters on the FFT
+#   bin centres, each scaled by 2 / (f[i+2] - f[i]);  power_to_db: 10 log10(max(S, 1e-10)) - 10 log10(max(1e-10,
+#   ref)), then clipped at (max - 80 dB).
+def hz_to_mel(f):
+    f = np.asarray(f, dtype=np.float64)
+    f_sp = 200.0 / 3
+    mels = f / f_sp
+    min_log_hz, min_log_mel, logstep = 1000.0, 1000.0 / f_sp, np.log(6.4) / 27.0
+    return np.where(f >= min_log_hz, min_log_mel + np.log(np.maximum(f, 1e-30) / min_log_hz) / logstep, mels)
+
+
+def mel_to_hz(m):
+    m = np.asarray(m, dtype=np.float64)
+    f_sp = 200.0 / 3
+    min_log_hz, min_log_mel, logstep = 1000.0, 1000.0 / f_sp, np.log(6.4) / 27.0
+    return np.where(m >= min_log_mel, min_log_hz * np.exp(logstep * (m - min_log_mel)), f_sp * m)
+
+
+def mel_filterbank(sr=24000, n_fft=N_FFT, n_mels=128):
+    """(n_mels, 1 + n_fft//2) float32, Slaney-normalised"""
+    fmax = sr / 2.0
+    fftfreqs = np.linspace(0, fmax, 1 + n_fft // 2, endpoint=True)
+    mel_f = mel_to_hz(np.linspace(hz_to_mel(0.0), hz_to_mel(fmax), n_mels + 2))
+    fdiff = np.diff(mel_f)
+    ramps = mel_f[:, None] - fftfreqs[None, :]
+    w = np.zeros((n_mels, 1 + n_fft // 2))
+    for i in range(n_mels):
+        lower = -ramps[i] / fdiff[i]
+        upper = ramps[i + 2] / fdiff[i + 1]
+        w[i] = np.maximum(0, np.minimum(lower, upper))
+    w *= (2.0 / (mel_f[2:n_mels + 2] - mel_f[:n_mels]))[:, None]
+    return w.astype(np.float32)
+
+
+def log_mel_spectrogram(sample, sampling_rate=24000, window_ms=10, step_ms=5, n_mels=128, top_db=80.0):
+    """(128, T) float32 in dB relative to the maximum"""
+    nperseg = int(round(window_ms * sampling_rate / 1e3))
+    hop = int(round(step_ms * sampling_rate / 1e3))
+    S = stft_complex(sample, hop=hop, win_length=nperseg)
+    power = (np.abs(S) ** 2).astype(np.float32)
+    mel = mel_filterbank(sampling_rate, N_FFT, n_mels).dot(power)
+    amin = 1e-10
+    ref = np.max(mel)
+    db = 10.0 * np.log10(np.maximum(amin, mel)) - 10.0 * np.log10(np.maximum(amin, ref))
+    return np.maximum(db, db.max() - top_db).astype(np.float32)

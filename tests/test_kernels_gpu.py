@@ -1,6 +1,8 @@
 """GPU parity of every HIP operator, called through the C-ABI (ctypes), against plain PyTorch
 fp64/fp32 CPU references of the same op.  Tolerances: 1e-4 relative to the tensor's max for fp32
 GEMM-type ops (the north star allows 1e-3 end to end), exact for integer/argmax work."""
+import math
+
 import numpy as np
 import pytest
 import torch
@@ -355,3 +357,20 @@ def test_stft_logpower_vs_oracle(L):
         ref = log_power_spectrogram(waves[i])
         assert spec[i].shape == ref.shape == (256, 1 + (L - 1) // 120)
         assert np.abs(spec[i] - ref).max() < 2e-3      # log-power domain, fp32 DFT vs fp64 FFT
+
+
+def test_log_mel_spectrogram_vs_oracle():
+    """spec_type='logms': STFT kernel + mel GEMM + max-referenced dB, against the NumPy oracle"""
+    from oracle.stft import log_mel_spectrogram
+    from attention_based_tbn_amd.core.dataset import Spectrogram
+    g = torch.Generator().manual_seed(3)
+    L = int(1.279 * 24000)
+    wave = torch.randn(3, L, generator=g) * 0.1
+    t = torch.arange(L) / 24000.0
+    wave[1] += torch.sin(2 * math.pi * 1500.0 * t)
+    got = Spectrogram(spec_type="logms")(wave.to(DEV)).cpu().numpy()
+    assert got.shape == (3, 128, 256)
+    for i in range(3):
+        want = log_mel_spectrogram(wave[i].numpy())
+        assert abs(got[i].max()) < 1e-5 and got[i].min() >= -80.0 - 1e-3
+        assert np.abs(got[i] - want).max() < 2e-3, i          # dB

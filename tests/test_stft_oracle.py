@@ -56,3 +56,38 @@ def test_trim_clamps_and_centres():
     assert seg[0] == 0
     seg, _ = trim_audio(a, frame_idx=60 * 100, audio_length=1.279)
     assert seg[-1] == 99999
+
+
+# ---- spec_type "logms" (dataset.py:496-506); librosa absent: known-answer tests of the restated algorithm ------------
+def test_mel_filterbank_known_answers():
+    from oracle.stft import hz_to_mel, mel_filterbank, mel_to_hz
+    from attention_based_tbn_amd.core.dataset.spectrogram import mel_filterbank as product_fb
+    fb = mel_filterbank(24000, 511, 128)
+    assert fb.shape == (128, 256) and fb.dtype == np.float32 and (fb >= 0).all()
+    assert np.array_equal(fb, product_fb(24000, 511, 128))          # the product builds the same basis
+    # Slaney scale: linear (200/3 Hz per mel) below 1 kHz, logarithmic above; exact inverse pair
+    assert abs(hz_to_mel(1000.0) - 15.0) < 1e-12 and abs(hz_to_mel(500.0) - 7.5) < 1e-12
+    assert abs(mel_to_hz(hz_to_mel(6400.0)) - 6400.0) < 1e-9 and abs(hz_to_mel(6400.0) - 42.0) < 1e-9
+    # triangles: peaks move monotonically up in frequency, every filter is non-empty, neighbours overlap
+    peaks = fb.argmax(1)
+    assert (np.diff(peaks) >= 0).all() and peaks[0] <= 2 and peaks[-1] >= 245
+    assert (fb.sum(1) > 0).all()
+    # Slaney normalisation: each triangle has (nearly) unit area in Hz -> sum * bin width ~ 1 once it spans a few bins
+    binw = 12000.0 / 255
+    area = fb.sum(1) * binw
+    assert np.all(np.abs(area[80:] - 1.0) < 0.05)      # narrow low-frequency triangles straddle 1-2 FFT bins
+
+
+def test_log_mel_spectrogram_known_answers():
+    from oracle.stft import log_mel_spectrogram, mel_filterbank
+    sr, f0 = 24000, 3000.0
+    t = np.arange(int(1.279 * sr)) / sr
+    db = log_mel_spectrogram(np.sin(2 * np.pi * f0 * t).astype(np.float32))
+    assert db.shape == (128, 256) and db.dtype == np.float32
+    assert abs(db.max()) < 1e-6 and db.min() >= -80.0 - 1e-4            # relative to the maximum, clipped at -80 dB
+    fb = mel_filterbank()
+    want_bin = int(np.argmax(fb[:, int(round(f0 / (12000.0 / 255)))]))
+    assert abs(int(np.argmax(db[:, 128])) - want_bin) <= 1              # the tone lands in its mel band
+    # doubling the amplitude leaves a max-referenced dB map unchanged
+    db2 = log_mel_spectrogram((2 * np.sin(2 * np.pi * f0 * t)).astype(np.float32))
+    assert np.abs(db2 - db)[db > -70].max() < 1e-3
