@@ -700,7 +700,10 @@ int tbn_launch_conv(ConvP p, int rowmode, int mt, int nt, hipStream_t st) {
   for (int i = 0; i < p.nseg; ++i) {
     const int cols = (i + 1 < p.nseg ? p.seg[i + 1].col_begin : p.Cout) - p.seg[i].col_begin;
     const size_t ob = (((size_t)p.N * p.OH * p.OW - 1) * p.seg[i].ld + cols) * sizeof(float);
-    TBN_REQUIRE(ob < (1ull << 31) && p.seg[i].ld % 1 == 0, "conv: output extent %zu B >= 2 GiB (process the frames in chunks)", ob);
+    TBN_REQUIRE(ob < (1ull << 31), "conv: output extent %zu B >= 2 GiB (process the frames in chunks)", ob);
+    // the epilogue picks the destination per 32-column sub-tile: segments must start on 32-column boundaries
+    TBN_REQUIRE(i == 0 || p.seg[i].col_begin % 32 == 0, "conv: segment %d starts at column %d (must be a multiple of 32)",
+                i, p.seg[i].col_begin);
     p.seg_bytes[i] = (unsigned)ob;
   }
   const int taps_full = rowmode ? p.R : p.R * p.S;
