@@ -89,6 +89,10 @@ int pool_out(int in, int k, int stride, int pad, bool ceil_mode) {
 struct tbn_backbone_plan {
   int cin0, frames, H, W;
   int cp, kw;  // stem channel padding / padded filter-row length
+  // stem conv as executed: 7 filter rows / stride 2 / pad 3 on the (H, W, cp) image, or -- one input channel, even
+  // H and W -- 4 rows / stride 1 / pad 2 on the 2x2 space-to-depth image (H/2, W/2, 4), see pool.hip
+  bool s2d;
+  int stem_rows, stem_stride, stem_pad, stem_H, stem_W;
   std::vector<Buf> bufs;
   std::vector<Conv> convs;
   std::vector<Pool> pools;
@@ -175,8 +179,15 @@ bool build_graph(tbn_backbone_plan* P) {
   const int cin0 = P->cin0;
   P->cp = (cin0 + 3) / 4 * 4;
   P->kw = (7 * P->cp + 31) / 32 * 32;
+  P->s2d = cin0 == 1 && P->H % 2 == 0 && P->W % 2 == 0;
+  P->stem_rows = P->s2d ? 4 : 7;
+  P->stem_stride = P->s2d ? 1 : 2;
+  P->stem_pad = P->s2d ? 2 : 3;
+  P->stem_H = P->s2d ? P->H / 2 : P->H;
+  P->stem_W = P->s2d ? P->W / 2 : P->W;
+  if (P->s2d) P->kw = 32;   // 4 pixels x 4 parities = 16 real slots
   P->weight_floats = P->chan_floats = 0;
-  const int x0 = add_buf(P, P->H, P->W, P->cp);
+  const int x0 = add_buf(P, P->H, P->W, P->cp);   // logical extent; the s2d layout has the same number of floats
   // stem
   int h1 = (P->H + 6 - 7) / 2 + 1, w1 = (P->W + 6 - 7) / 2 + 1;
   const int c1 = add_buf(P, h1, w1, 64);
@@ -359,13 +370,13 @@ void plan_memory(tbn_backbone_plan* P) {
   size_t partial = 0, wsplit = 0, wtf = 0;
   for (auto& c : P->convs) {
     const int M = (int)(R * c.outH * c.outW);
-    const int K = c.stem ? 7 * P->kw : c.k * c.k * c.cin;
+    const int K = c.stem ? P->stem_rows * P->kw : c.k * c.k * c.cin;
     tbn_conv_pick_tile(M, c.cout, K, &c.mt, &c.nt);
     size_t a = (size_t)cdiv(M, 128) * 2 * c.cout;  // worst case (mt = 1): autotune may pick any tile
     size_t bparts = (size_t)tbn_bn_bwd_parts(M, c.cout) * 2 * c.cout;
     if (a > partial) partial = a;
     if (bparts > partial) partial = bparts;
-    const int taps = c.stem ? 7 : c.k * c.k, ci = c.stem ? P->kw : c.cin;
+    const int taps = c.stem ? P->stem_rows : c.k * c.k, ci = c.stem ? P->kw : c.cin;
     size_t ws = tbn_wgrad_workspace_floats(M, c.cout, ci, taps);
     if (ws > wsplit) wsplit = ws;
     if (c.need_dgrad) {
@@ -560,8 +571,13 @@ int tbn_backbone_forward(const tbn_backbone_plan* P, int training, const float* 
   float* shift = scale + P->chan_floats;
   float* wpack = ws + P->wpack_off;
 
-  TBN_TRY(tbn_launch_nchw_to_nhwc_pad(x_nchw, ws + P->x0_off, R, P->cin0, P->H, P->W, P->cp, st));
-  TBN_TRY(tbn_launch_pack_stem_weight(prm->weight + P->convs[0].w_off, wpack, 64, P->cin0, P->cp, P->kw, st));
+  if (P->s2d) {
+    TBN_TRY(tbn_launch_nchw1_to_s2d(x_nchw, ws + P->x0_off, R, P->H, P->W, st));
+    TBN_TRY(tbn_launch_pack_stem_weight_s2d(prm->weight + P->convs[0].w_off, wpack, 64, st));
+  } else {
+    TBN_TRY(tbn_launch_nchw_to_nhwc_pad(x_nchw, ws + P->x0_off, R, P->cin0, P->H, P->W, P->cp, st));
+    TBN_TRY(tbn_launch_pack_stem_weight(prm->weight + P->convs[0].w_off, wpack, 64, P->cin0, P->cp, P->kw, st));
+  }
   if (!training)
     TBN_TRY(tbn_launch_bn_fold(prm->gamma, prm->beta, prm->running_mean, prm->running_var, prm->bias, prm->eps, scale,
                                shift, (int)P->chan_floats, st));
@@ -591,10 +607,14 @@ int tbn_backbone_forward(const tbn_backbone_plan* P, int training, const float* 
       if (c.stem) {
         p.wt = wpack;
         p.Cin = P->kw;
-        p.R = 7;
+        p.R = P->stem_rows;
         p.S = 1;
-        p.K = 7 * P->kw;
+        p.K = P->stem_rows * P->kw;
         p.cp = P->cp;
+        p.H = P->stem_H;          // s2d: the 4-row / stride-1 conv on the space-to-depth image
+        p.W = P->stem_W;
+        p.stride = P->stem_stride;
+        p.pad = P->stem_pad;
       } else {
         p.wt = prm->weight + c.w_off;
         p.Cin = c.cin;
@@ -753,10 +773,14 @@ int tbn_backbone_autotune(tbn_backbone_plan* P, int training, const tbn_backbone
         if (c.stem) {
           p.wt = ws + P->wpack_off;
           p.Cin = P->kw;
-          p.R = 7;
+          p.R = P->stem_rows;
           p.S = 1;
-          p.K = 7 * P->kw;
+          p.K = P->stem_rows * P->kw;
           p.cp = P->cp;
+          p.H = P->stem_H;          // s2d: the 4-row / stride-1 conv on the space-to-depth image
+          p.W = P->stem_W;
+          p.stride = P->stem_stride;
+          p.pad = P->stem_pad;
         } else {
           p.wt = prm->weight + c.w_off;
           p.Cin = c.cin;
@@ -998,13 +1022,20 @@ int tbn_backbone_backward(const tbn_backbone_plan* P, const float* dfeatures, co
       wp.alg_flops = 2.0 * M * (double)c.cout * c.k * c.k * c.cin;
       if (c.stem) {
         wp.Cin = P->kw;
-        wp.R = 7;
+        wp.R = P->stem_rows;
         wp.S = 1;
-        wp.taps = 7;
+        wp.taps = P->stem_rows;
         wp.cp = P->cp;
+        wp.H = P->stem_H;
+        wp.W = P->stem_W;
+        wp.stride = P->stem_stride;
+        wp.pad = P->stem_pad;
         float* dwp = ws + P->dwpack_off;
         TBN_TRY(tbn_launch_wgrad(wp, 1, dwp, ws + P->wsplit_off, wst));
-        TBN_TRY(tbn_launch_unpack_stem_wgrad(dwp, g->dweight + c.w_off, 64, P->cin0, P->cp, P->kw, wst));
+        if (P->s2d)
+          TBN_TRY(tbn_launch_unpack_stem_wgrad_s2d(dwp, g->dweight + c.w_off, 64, wst));
+        else
+          TBN_TRY(tbn_launch_unpack_stem_wgrad(dwp, g->dweight + c.w_off, 64, P->cin0, P->cp, P->kw, wst));
       } else {
         wp.Cin = c.cin;
         wp.R = wp.S = c.k;

@@ -286,3 +286,65 @@ int tbn_launch_unpack_stem_wgrad(const float* dwp, float* dw, int Cout, int Cin,
   TBN_CHECK_LAUNCH("unpack_stem_wgrad");
   return TBN_OK;
 }
+
+// ---------------------------------------------------------------- single-channel stem as a space-to-depth conv
+// A 7x7 / stride 2 / pad 3 conv on ONE input channel (the audio spectrogram) wastes 25 of the 32 k-slots of a
+// padded filter row.  It is exactly a 4x4 / stride 1 conv on the 2x2 space-to-depth image (4 channels = the pixel
+// parities (y&1, x&1), half the height / width): x[2oy-3+r] with r+1 = 2a+py reads s2d row oy-2+a, parity py, so the
+// taps are a, b in 0..3 with "pad 2" on the top / left (a = py = 0 has no source tap: zero weight).  A filter row is
+// then 4 pixels x 4 parities = 16 real of 32 slots and K = 4 x 32 instead of 7 x 32.
+__global__ __launch_bounds__(256) void nchw1_to_s2d_kernel(const float* __restrict__ in, float* __restrict__ out, int N,
+                                                           int H, int W) {
+  const int H2 = H >> 1, W2 = W >> 1;
+  const size_t total = (size_t)N * H2 * W2;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int X = (int)(i % W2);
+    size_t t = i / W2;
+    const int Y = (int)(t % H2), n = (int)(t / H2);
+    const float* r0 = in + ((size_t)n * H + 2 * Y) * W + 2 * X;
+    const float2 a = *reinterpret_cast<const float2*>(r0);          // W even, 2X even: 8-byte aligned
+    const float2 b = *reinterpret_cast<const float2*>(r0 + W);
+    reinterpret_cast<float4*>(out)[i] = make_float4(a.x, a.y, b.x, b.y);   // channel = py*2 + px
+  }
+}
+
+int tbn_launch_nchw1_to_s2d(const float* in, float* out, int N, int H, int W, hipStream_t st) {
+  TBN_REQUIRE(H % 2 == 0 && W % 2 == 0, "nchw1_to_s2d: H and W must be even");
+  hipLaunchKernelGGL(nchw1_to_s2d_kernel, dim3(ew_grid((size_t)N * (H / 2) * (W / 2))), dim3(256), 0, st, in, out, N, H,
+                     W);
+  TBN_CHECK_LAUNCH("nchw1_to_s2d");
+  return TBN_OK;
+}
+
+// weights [Cout][7][7] -> [Cout][4][32]: slot (a, b*4 + py*2 + px) = w[2a+py-1][2b+px-1] (zero outside 0..6, zero tail)
+__global__ void pack_stem_weight_s2d_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout) {
+  const int total = Cout * 4 * 32;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int k = i & 31, a = (i >> 5) & 3, co = i >> 7;
+    float v = 0.f;
+    if (k < 16) {
+      const int b = k >> 2, py = (k >> 1) & 1, px = k & 1;
+      const int r = 2 * a + py - 1, s2 = 2 * b + px - 1;
+      if (r >= 0 && r < 7 && s2 >= 0 && s2 < 7) v = w[(co * 7 + r) * 7 + s2];
+    }
+    wp[i] = v;
+  }
+}
+__global__ void unpack_stem_wgrad_s2d_kernel(const float* __restrict__ dwp, float* __restrict__ dw, int Cout) {
+  const int total = Cout * 49;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int s2 = i % 7, r = (i / 7) % 7, co = i / 49;
+    const int a = (r + 1) >> 1, py = (r + 1) & 1, b = (s2 + 1) >> 1, px = (s2 + 1) & 1;
+    dw[i] = dwp[(co * 4 + a) * 32 + b * 4 + py * 2 + px];
+  }
+}
+int tbn_launch_pack_stem_weight_s2d(const float* w, float* wp, int Cout, hipStream_t st) {
+  hipLaunchKernelGGL(pack_stem_weight_s2d_kernel, dim3(cdiv(Cout * 128, 256)), dim3(256), 0, st, w, wp, Cout);
+  TBN_CHECK_LAUNCH("pack_stem_weight_s2d");
+  return TBN_OK;
+}
+int tbn_launch_unpack_stem_wgrad_s2d(const float* dwp, float* dw, int Cout, hipStream_t st) {
+  hipLaunchKernelGGL(unpack_stem_wgrad_s2d_kernel, dim3(cdiv(Cout * 49, 256)), dim3(256), 0, st, dwp, dw, Cout);
+  TBN_CHECK_LAUNCH("unpack_stem_wgrad_s2d");
+  return TBN_OK;
+}

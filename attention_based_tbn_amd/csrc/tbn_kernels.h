@@ -159,5 +159,8 @@ int tbn_launch_spatial_mean_fwd(const float* in, int in_ld, float* out, int out_
 int tbn_launch_spatial_mean_bwd(const float* dout, int dout_ld, float* din, int din_ld, int N, int H, int W, int C,
                                 int freq_only, hipStream_t st);
 int tbn_launch_nchw_to_nhwc_pad(const float* in, float* out, int N, int C, int H, int W, int Cp, hipStream_t st);
+int tbn_launch_nchw1_to_s2d(const float* in, float* out, int N, int H, int W, hipStream_t st);
+int tbn_launch_pack_stem_weight_s2d(const float* w, float* wp, int Cout, hipStream_t st);
+int tbn_launch_unpack_stem_wgrad_s2d(const float* dwp, float* dw, int Cout, hipStream_t st);
 int tbn_launch_pack_stem_weight(const float* w, float* wp, int Cout, int Cin, int Cp, int KW, hipStream_t st);
 int tbn_launch_unpack_stem_wgrad(const float* dwp, float* dw, int Cout, int Cin, int Cp, int KW, hipStream_t st);
