@@ -216,3 +216,40 @@ def test_plan_create_accepts_exactly_the_sizes_the_reference_graph_accepts():
             else:
                 assert b"not a valid BN-Inception size" in L.tbn_last_error()
     assert seen == {True, False}
+
+
+def test_c_abi_rejects_bad_arguments_before_touching_the_gpu():
+    """argument validation happens on the host, ahead of any launch: every call below must fail with a negative
+    status and a message -- and must not need a GPU to do so"""
+    import ctypes as C
+    from attention_based_tbn_amd._lib import OptTensor, lib
+    L = lib()
+    bad = 0x1000   # never dereferenced: validation fails first
+
+    def fails(rc, needle):
+        assert rc < 0, rc
+        msg = L.tbn_last_error().decode()
+        assert needle in msg, msg
+
+    h = C.c_void_p()
+    fails(L.tbn_backbone_plan_create(3, 1, 16, 16, C.byref(h)), "unsupported shape")
+    fails(L.tbn_backbone_plan_create(3, 1, 75, 91, C.byref(h)), "not a valid BN-Inception size")
+    # frames pipeline: box / crop outside their parent, stack not dividing the frame count
+    fails(L.tbn_frames_to_tensor(bad, 4, 64, 64, 3, 10, 10, 60, 60, 32, 32, 0, 0, 32, 32, 0, 1, None, None, 0, 1, bad, None),
+          "outside the 64x64 frame")
+    fails(L.tbn_frames_to_tensor(bad, 4, 64, 64, 3, 0, 0, 64, 64, 32, 32, 8, 8, 32, 32, 0, 1, None, None, 0, 1, bad, None),
+          "outside the resized")
+    fails(L.tbn_frames_to_tensor(bad, 7, 64, 64, 1, 0, 0, 64, 64, 64, 64, 0, 0, 64, 64, 0, 10, None, None, 0, 1, bad, None),
+          "bad frame stack")
+    # optimiser: too many tensors in one call, unaligned pointer, null gradient
+    many = (OptTensor * 49)(*[OptTensor(bad, bad, bad, 4)] * 49)
+    fails(L.tbn_opt_sgd_step(many, 49, 0.1, 0.9, 0.0, None, None), "tensors per call")
+    one = (OptTensor * 1)(OptTensor(bad, bad + 2, bad, 4))
+    fails(L.tbn_opt_sgd_step(one, 1, 0.1, 0.9, 0.0, None, None), "4-byte aligned")
+    one = (OptTensor * 1)(OptTensor(bad, 0, bad, 4))
+    fails(L.tbn_opt_sqnorm_partials(one, 1, bad, None), "null pointer")
+    # metrics: k larger than the number of classes
+    fails(L.tbn_topk_correct(bad, 10, bad, 4, 10, 11, bad, None, None, None), "bad shape")
+    # conv: K not a multiple of 32 (cin = 10, 3x3)
+    fails(L.tbn_conv2d_fwd(bad, 10, bad, bad, bad, 64, 2, 8, 8, 10, 64, 3, 1, 1, 0, 0, None, None, None, None),
+          "multiples of 32")
