@@ -74,16 +74,14 @@ __device__ __forceinline__ float4 buf_load4(i32x4 r, unsigned voff, unsigned sof
 // EPI: 0 plain (+bias, optional ReLU / accumulate), 1 training-BN statistics, 2 eval-BN fold + ReLU,
 //      3 plain with output scatter (parity phase of a strided data gradient)
 template <int MT, int NT, bool ROWMODE, int EPI, int STAGES>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
+__device__ __forceinline__ void conv_igemm_body(const ConvP& p, const int bid, float* lds) {
   constexpr int BM = 128 * MT, BN = 32 * NT;
   constexpr int AR = 4 * MT;  // A rows per thread
   constexpr int TILE_F = (BM + BN) * LDT;  // floats per LDS stage (A rows then B rows)
-  __shared__ __attribute__((aligned(16))) float lds[STAGES * TILE_F];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // XCD-aware bijective remap: blocks b, b+8, ... share an XCD -> give them consecutive tiles
   const int nb = p.tiles_m * p.tiles_n;
-  const int bid = blockIdx.x;
   const int q8 = nb >> 3, r8 = nb & 7, xcd = bid & 7, idx = bid >> 3;
   const int nid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
   const int tm = nid / p.tiles_n, tn = nid - tm * p.tiles_n;
@@ -366,6 +364,27 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
       p.stat_partial[((size_t)tm * 2 + 1) * p.Cout + n0 + tid] = t2;
     }
   }
+}
+
+template <int MT, int NT, bool ROWMODE, int EPI, int STAGES>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
+  __shared__ __attribute__((aligned(16))) float lds[STAGES * (128 * MT + 32 * NT) * LDT];
+  conv_igemm_body<MT, NT, ROWMODE, EPI, STAGES>(p, blockIdx.x, lds);
+}
+
+// The four output-parity phases of a stride-2 data gradient in ONE launch: each phase alone is a small GEMM
+// (M / 4 rows, 1-4 taps) that leaves most CUs idle; a workgroup finds its phase by a scalar scan.
+struct ConvPhases {
+  ConvP ph[4];
+  int blk0[5];
+  int n;
+};
+template <int MT, int NT, int STAGES>
+__global__ __launch_bounds__(256) void conv_igemm_phases_kernel(ConvPhases q) {
+  __shared__ __attribute__((aligned(16))) float lds[STAGES * (128 * MT + 32 * NT) * LDT];
+  int ph = 0;
+  while (ph + 1 < q.n && (int)blockIdx.x >= q.blk0[ph + 1]) ++ph;
+  conv_igemm_body<MT, NT, false, 3, STAGES>(q.ph[ph], blockIdx.x - q.blk0[ph], lds);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -736,6 +755,8 @@ int tbn_launch_conv(ConvP p, int rowmode, int mt, int nt, hipStream_t st) {
   TBN_REQUIRE(!rowmode && p.stride == 1 && p.R == p.S && p.R * p.S <= 9, "conv: unsupported strided data gradient");
   const double flops_total = p.alg_flops;
   const int full_M = p.N * p.OH * p.OW;
+  static thread_local ConvPhases phases;   // ~2 KB kernel argument, built in place
+  phases.n = 0;
   for (int py = 0; py < 2; ++py)
     for (int px = 0; px < 2; ++px) {
       ConvP q = p;
@@ -780,9 +801,43 @@ int tbn_launch_conv(ConvP p, int rowmode, int mt, int nt, hipStream_t st) {
         continue;
       }
       q.K = q.ntaps * p.Cin;
-      int rc = launch_conv_tiles(q, 0, 0, 0, st);
-      if (rc != TBN_OK) return rc;
+      phases.ph[phases.n++] = q;
     }
+  if (phases.n == 0) return TBN_OK;
+  // one tile shape for all phases (picked on the largest one), one launch
+  int pmt = mt, pnt = nt;
+  if (pmt <= 0 || pnt <= 0) tbn_conv_pick_tile(phases.ph[0].M, p.Cout, phases.ph[0].K, &pmt, &pnt);
+  const int stages = (p.stages == 1 || p.stages == 2) ? p.stages : ((pmt == 1) ? 2 : 1);
+  phases.blk0[0] = 0;
+  for (int i = 0; i < phases.n; ++i) {
+    ConvP& q = phases.ph[i];
+    q.stages = stages;
+    q.tiles_m = cdiv(q.M, 128 * pmt);
+    q.tiles_n = cdiv(q.Cout, 32 * pnt);
+    phases.blk0[i + 1] = phases.blk0[i] + q.tiles_m * q.tiles_n;
+  }
+  {
+    char nm[64];
+    snprintf(nm, sizeof(nm), "conv_igemm_phases_kernel<%d, %d, %d>", pmt, pnt, stages);
+    tbn_prof_begin(nm, flops_total, st);
+  }
+#define TBN_PCASE(MTv, NTv)                                                                                        \
+  if (pmt == MTv && pnt == NTv) {                                                                                  \
+    if (stages == 2)                                                                                               \
+      hipLaunchKernelGGL((conv_igemm_phases_kernel<MTv, NTv, 2>), dim3(phases.blk0[phases.n]), dim3(256), 0, st,  \
+                         phases);                                                                                  \
+    else                                                                                                           \
+      hipLaunchKernelGGL((conv_igemm_phases_kernel<MTv, NTv, 1>), dim3(phases.blk0[phases.n]), dim3(256), 0, st,  \
+                         phases);                                                                                  \
+  } else
+  TBN_PCASE(1, 1) TBN_PCASE(1, 2) TBN_PCASE(1, 3) TBN_PCASE(1, 4) TBN_PCASE(2, 1) TBN_PCASE(2, 2) TBN_PCASE(2, 3)
+  TBN_PCASE(2, 4) {
+    tbn_set_error("conv: unsupported tile %dx%d", pmt, pnt);
+    return TBN_ERR_UNSUPPORTED;
+  }
+#undef TBN_PCASE
+  tbn_prof_end(st);
+  TBN_CHECK_LAUNCH("conv_igemm_phases");
   return TBN_OK;
 }
 

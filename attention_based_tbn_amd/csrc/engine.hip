@@ -752,7 +752,7 @@ int tbn_backbone_autotune(tbn_backbone_plan* P, int training, const tbn_backbone
   for (auto& c : P->convs) {
     const Buf& ib = P->bufs[c.inbuf];
     for (int pass = 0; pass < 2 && rc == TBN_OK; ++pass) {  // 0: forward, 1: data gradient
-      if (pass == 1 && (!training || !c.need_dgrad || c.stride != 1)) continue;
+      if (pass == 1 && (!training || !c.need_dgrad)) continue;
       ConvP p;
       memset(&p, 0, sizeof(p));
       p.N = R;
@@ -815,6 +815,7 @@ int tbn_backbone_autotune(tbn_backbone_plan* P, int training, const tbn_backbone
         p.R = p.S = c.k;
         p.stride = 1;
         p.pad = c.k - 1 - c.pad;
+        p.up = c.stride;      // stride-2 layers: the four parity phases in one launch
         p.M = R * c.inH * c.inW;
         p.K = c.k * c.k * c.cout;
         p.mode = CONV_EPI_PLAIN;
