@@ -433,7 +433,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
   const int pbeg = split * p.rows_per_split;
   const int pend = min(p.M, pbeg + p.rows_per_split);
 
-  constexpr int KS = 4 / (MT * NT) > 0 ? 4 / (MT * NT) : 1;  // K-split accumulators per sub-tile (see the main loop)
+  // K-split accumulators per sub-tile so that >= 4 independent accumulators rotate (see the main loop)
+  constexpr int KS = (MT * NT >= 4) ? 1 : (MT * NT == 1 ? 4 : 2);
   f32x16 acc[MT][NT][KS];
 #pragma unroll
   for (int i = 0; i < MT; ++i)
@@ -531,12 +532,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
               __builtin_amdgcn_mfma_f32_32x32x2f32(a[kp & 1][i], bb[kp & 1][j], acc[i][j][kp % KS], 0, 0, 0);
     }
     {
-      constexpr int NM = MT * NT;   // the (MT + NT) b32 fragment reads of a k-pair are 2 DS instructions
-      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+      constexpr int NM = MT * NT;
+      constexpr int NRD = (MT + 1) / 2 + (NT + 1) / 2;   // b32 fragment reads are merged pairwise into ds_read2_b32
+      __builtin_amdgcn_sched_group_barrier(0x100, 2 * NRD, 0);
 #pragma unroll
       for (int g = 0; g < KR / 2 - 2; ++g) {
         __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
       }
       __builtin_amdgcn_sched_group_barrier(0x008, 2 * NM, 0);
     }
@@ -846,7 +848,9 @@ static void launch_wgrad(const WgradP& p, int blocks, hipStream_t st) {
   hipLaunchKernelGGL((conv_wgrad_kernel<MT, NT, RM>), dim3(blocks), dim3(256), 0, st, p);
 }
 
-static int pick_wtile(int c) { return (c % 64 == 0 || c > 96) ? 2 : 1; }
+// 32-column sub-tiles per workgroup along one dimension: 3 for 96 (and other odd multiples of 96), else 2 when the
+// extent is a multiple of 64 or large, else 1
+static int pick_wtile(int c) { return (c % 96 == 0 && c % 64 != 0) ? 3 : ((c % 64 == 0 || c > 96) ? 2 : 1); }
 
 // plan: tile + split-K so that the grid has >= ~3 workgroups per CU and every split >= 256 rows
 void tbn_wgrad_plan(int M, int Cout, int Cin, int taps, int* mt, int* nt, int* splits, int* rows_per_split) {
@@ -905,7 +909,8 @@ int tbn_launch_wgrad(WgradP p, int rowmode, float* dw, float* workspace, hipStre
     else                                                            \
       launch_wgrad<MTv, NTv, false>(p, blocks, st);                 \
   } else
-  TBN_CASE(1, 1) TBN_CASE(1, 2) TBN_CASE(2, 1) TBN_CASE(2, 2) {
+  TBN_CASE(1, 1) TBN_CASE(1, 2) TBN_CASE(1, 3) TBN_CASE(2, 1) TBN_CASE(2, 2) TBN_CASE(2, 3) TBN_CASE(3, 1) TBN_CASE(3, 2)
+  TBN_CASE(3, 3) {
     tbn_set_error("wgrad: unsupported tile");
     return TBN_ERR_UNSUPPORTED;
   }
