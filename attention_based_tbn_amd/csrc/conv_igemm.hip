@@ -852,10 +852,10 @@ static void launch_wgrad(const WgradP& p, int blocks, hipStream_t st) {
 // extent is a multiple of 64 or large, else 1
 static int pick_wtile(int c) { return (c % 96 == 0 && c % 64 != 0) ? 3 : ((c % 64 == 0 || c > 96) ? 2 : 1); }
 
-// plan: tile + split-K so that the grid has >= ~3 workgroups per CU and every split >= 256 rows
+// plan: tile (0 = heuristic) + split-K so that the grid has >= ~3 workgroups per CU and every split >= 256 rows
 void tbn_wgrad_plan(int M, int Cout, int Cin, int taps, int* mt, int* nt, int* splits, int* rows_per_split) {
-  *mt = pick_wtile(Cout);
-  *nt = pick_wtile(Cin);
+  if (*mt < 1 || *mt > 3) *mt = pick_wtile(Cout);
+  if (*nt < 1 || *nt > 3) *nt = pick_wtile(Cin);
   const int tiles = cdiv(Cout, 32 * *mt) * cdiv(Cin, 32 * *nt) * taps;
   int want = cdiv(768, tiles);
   int max_splits = cdiv(M, 256);
@@ -868,10 +868,17 @@ void tbn_wgrad_plan(int M, int Cout, int Cin, int taps, int* mt, int* nt, int* s
   *rows_per_split = rps;
 }
 
+// split-K slab floats: the worst case over every tile the autotuner may choose
 size_t tbn_wgrad_workspace_floats(int M, int Cout, int Cin, int taps) {
-  int mt, nt, s, rps;
-  tbn_wgrad_plan(M, Cout, Cin, taps, &mt, &nt, &s, &rps);
-  return s > 1 ? (size_t)s * Cout * taps * Cin : 0;
+  size_t worst = 0;
+  for (int mt = 1; mt <= 3; ++mt)
+    for (int nt = 1; nt <= 3; ++nt) {
+      int m = mt, n = nt, s, rps;
+      tbn_wgrad_plan(M, Cout, Cin, taps, &m, &n, &s, &rps);
+      const size_t need = s > 1 ? (size_t)s * Cout * taps * Cin : 0;
+      if (need > worst) worst = need;
+    }
+  return worst;
 }
 
 int tbn_launch_wgrad(WgradP p, int rowmode, float* dw, float* workspace, hipStream_t st) {
@@ -885,7 +892,7 @@ int tbn_launch_wgrad(WgradP p, int rowmode, float* dw, float* workspace, hipStre
     p.x_bytes = (unsigned)xb;
     p.dy_bytes = (unsigned)db;
   }
-  int mt, nt, splits, rps;
+  int mt = p.mt, nt = p.nt, splits, rps;   // 0: heuristic tile
   tbn_wgrad_plan(p.M, p.Cout, p.Cin, p.taps, &mt, &nt, &splits, &rps);
   p.K = p.taps * p.Cin;
   p.tiles_co = cdiv(p.Cout, 32 * mt);

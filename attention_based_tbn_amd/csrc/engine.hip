@@ -55,6 +55,7 @@ struct Conv {
   size_t y_off;
   int mt, nt, stages = 0;       // forward tile / LDS stages (0 = default)
   int d_mt, d_nt, d_stages = 0; // dgrad tile
+  int w_mt = 0, w_nt = 0;       // wgrad tile (0 = heuristic)
   bool stem;
   bool dgrad_accum;    // dgrad adds into d(inbuf)
   bool need_dgrad;
@@ -731,6 +732,44 @@ int tbn_backbone_forward(const tbn_backbone_plan* P, int training, const float* 
   return TBN_OK;
 }
 
+// weight-gradient launch parameters of one conv (shared by backward and autotune)
+static void fill_wgrad(const tbn_backbone_plan* P, const Conv& c, float* ws, int R, WgradP* wp) {
+  const Buf& ib = P->bufs[c.inbuf];
+  memset(wp, 0, sizeof(*wp));
+  wp->dy = ws + c.y_off;
+  wp->dy_ld = c.cout;
+  wp->x = ws + ib.off;
+  wp->x_ld = ib.C;
+  wp->N = R;
+  wp->H = c.inH;
+  wp->W = c.inW;
+  wp->OH = c.outH;
+  wp->OW = c.outW;
+  wp->Cout = c.cout;
+  wp->stride = c.stride;
+  wp->pad = c.pad;
+  wp->M = R * c.outH * c.outW;
+  wp->alg_flops = 2.0 * wp->M * (double)c.cout * c.k * c.k * c.cin;
+  wp->mt = c.w_mt;
+  wp->nt = c.w_nt;
+  if (c.stem) {
+    wp->Cin = P->kw;
+    wp->R = P->stem_rows;
+    wp->S = 1;
+    wp->taps = P->stem_rows;
+    wp->cp = P->cp;
+    wp->H = P->stem_H;
+    wp->W = P->stem_W;
+    wp->stride = P->stem_stride;
+    wp->pad = P->stem_pad;
+  } else {
+    wp->Cin = c.cin;
+    wp->R = wp->S = c.k;
+    wp->taps = c.k * c.k;
+  }
+}
+
+
 // One-time tile autotuning: times every (MT, NT) tile of the forward and data-gradient implicit GEMM
 // of each layer on the real shapes (2 launches each, hipEvents) and stores the fastest in the plan.
 // Synchronises the stream (the only entry point that does); activations in `workspace` are clobbered.
@@ -822,6 +861,9 @@ int tbn_backbone_autotune(tbn_backbone_plan* P, int training, const tbn_backbone
         p.seg[0].ptr = ws + ib.doff;
         p.seg[0].ld = ib.C;
       }
+      // fastest of the candidates in isolation.  (Measured alternatives that lost: preferring the largest tile
+      // within 3-15 % of the fastest -- monotonically slower steps; autotuning the weight-gradient tile the same
+      // way -- 0.4 % slower than the size heuristic of tbn_wgrad_plan.)
       float best = 1e30f;
       int bm = 1, bn = 1, bs = 2;
       for (int mt = 1; mt <= 2 && rc == TBN_OK; ++mt)
@@ -1006,31 +1048,8 @@ int tbn_backbone_backward(const tbn_backbone_plan* P, const float* dfeatures, co
     }
     {
       WgradP wp;
-      memset(&wp, 0, sizeof(wp));
-      wp.dy = dconv;
-      wp.dy_ld = c.cout;
-      wp.x = ws + ib.off;
-      wp.x_ld = ib.C;
-      wp.N = R;
-      wp.H = c.inH;
-      wp.W = c.inW;
-      wp.OH = c.outH;
-      wp.OW = c.outW;
-      wp.Cout = c.cout;
-      wp.stride = c.stride;
-      wp.pad = c.pad;
-      wp.M = M;
-      wp.alg_flops = 2.0 * M * (double)c.cout * c.k * c.k * c.cin;
+      fill_wgrad(P, c, ws, R, &wp);
       if (c.stem) {
-        wp.Cin = P->kw;
-        wp.R = P->stem_rows;
-        wp.S = 1;
-        wp.taps = P->stem_rows;
-        wp.cp = P->cp;
-        wp.H = P->stem_H;
-        wp.W = P->stem_W;
-        wp.stride = P->stem_stride;
-        wp.pad = P->stem_pad;
         float* dwp = ws + P->dwpack_off;
         TBN_TRY(tbn_launch_wgrad(wp, 1, dwp, ws + P->wsplit_off, wst));
         if (P->s2d)
@@ -1038,9 +1057,6 @@ int tbn_backbone_backward(const tbn_backbone_plan* P, const float* dfeatures, co
         else
           TBN_TRY(tbn_launch_unpack_stem_wgrad(dwp, g->dweight + c.w_off, 64, P->cin0, P->cp, P->kw, wst));
       } else {
-        wp.Cin = c.cin;
-        wp.R = wp.S = c.k;
-        wp.taps = c.k * c.k;
         TBN_TRY(tbn_launch_wgrad(wp, 0, g->dweight + c.w_off, ws + P->wsplit_off, wst));
       }
     }

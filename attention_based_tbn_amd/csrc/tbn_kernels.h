@@ -55,6 +55,7 @@ struct WgradP {
   int cp;
   int tiles_co, tiles_ci;
   int rows_per_split;
+  int mt, nt;             // host only: tile (32-column sub-tiles of Cout / Cin per workgroup), 0 = heuristic
   FastDiv div_ohw, div_ow;
   double alg_flops;       // host only
   unsigned dy_bytes, x_bytes;
