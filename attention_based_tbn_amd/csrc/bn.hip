@@ -268,6 +268,41 @@ __device__ __forceinline__ float4 pooled_grad(const PoolGrad& q, int p, int c) {
   const uint32_t n = fdiv(row, q.div_h);
   const int iy = (int)row - (int)n * q.H;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (q.stride == 2 && q.pad == 0) {
+    // 3x3 / stride 2 / pad 0 (every fused pool): an input pixel lies in window o = i >> 1 (tap i & 1) and, for even
+    // i, also in window o - 1 (tap 2).  All four candidates are evaluated branch-free with their loads issued
+    // together (the looped form below is latency-bound: 1.3 TB/s on the 308 MB stem tensors); invalid candidates
+    // read a clamped, in-range address and are masked.  Same summation order as the loops: (hi,hi) (hi,lo) (lo,hi) (lo,lo).
+    const int oyA = iy >> 1, ryA = iy & 1, oxA = ix >> 1, rxA = ix & 1;
+    const bool vyA = oyA < q.OH, vyB = (ryA == 0) && (oyA >= 1);
+    const bool vxA = oxA < q.OW, vxB = (rxA == 0) && (oxA >= 1);
+    const int oy[2] = {vyA ? oyA : 0, vyB ? oyA - 1 : 0}, ry[2] = {ryA, 2};
+    const int ox[2] = {vxA ? oxA : 0, vxB ? oxA - 1 : 0}, rx[2] = {rxA, 2};
+    const bool vy[2] = {vyA, vyB}, vx[2] = {vxA, vxB};
+    uint32_t am[4];
+    float4 d[4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const size_t opix = (size_t)((int)n * q.OH + oy[a]) * q.OW + ox[b];
+        am[a * 2 + b] = *reinterpret_cast<const uint32_t*>(q.argmax + opix * q.C + c);
+        d[a * 2 + b] = *reinterpret_cast<const float4*>(q.dout + opix * q.dout_ld + c);
+      }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const uint32_t k = (uint32_t)(ry[a] * 3 + rx[b]);
+        const uint32_t m = am[a * 2 + b];
+        const bool v = vy[a] && vx[b];
+        if (v && (m & 0xff) == k) acc.x += d[a * 2 + b].x;
+        if (v && ((m >> 8) & 0xff) == k) acc.y += d[a * 2 + b].y;
+        if (v && ((m >> 16) & 0xff) == k) acc.z += d[a * 2 + b].z;
+        if (v && (m >> 24) == k) acc.w += d[a * 2 + b].w;
+      }
+    return acc;
+  }
   const int oy_hi = min(q.OH - 1, (iy + q.pad) / q.stride);
   const int ox_hi = min(q.OW - 1, (ix + q.pad) / q.stride);
   for (int oy = oy_hi; oy >= 0; --oy) {
