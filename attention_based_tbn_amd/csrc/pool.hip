@@ -84,6 +84,35 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
     pix /= W;
     const int iy = (int)(pix % H), n = (int)(pix / H);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (stride == 2 && pad == 0) {
+      // the pass-through pools of inception_3c / 4e: branch-free form of the loops below (window i >> 1 with tap
+      // i & 1 and, for even i, window (i >> 1) - 1 with tap 2); all loads are issued together, same summation order
+      const int oyA = iy >> 1, ryA = iy & 1, oxA = ix >> 1, rxA = ix & 1;
+      const bool vy[2] = {oyA < OH, (ryA == 0) && (oyA >= 1)}, vx[2] = {oxA < OW, (rxA == 0) && (oxA >= 1)};
+      const int oy[2] = {vy[0] ? oyA : 0, vy[1] ? oyA - 1 : 0}, ry[2] = {ryA, 2};
+      const int ox[2] = {vx[0] ? oxA : 0, vx[1] ? oxA - 1 : 0}, rx[2] = {rxA, 2};
+      uint32_t am[4];
+      float4 d[4];
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          const size_t opix = (size_t)(n * OH + oy[a]) * OW + ox[b];
+          am[a * 2 + b] = *reinterpret_cast<const uint32_t*>(argmax + opix * C + g * 4);
+          d[a * 2 + b] = *reinterpret_cast<const float4*>(dout + opix * dout_ld + g * 4);
+        }
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          const uint32_t k = (uint32_t)(ry[a] * 3 + rx[b]), m = am[a * 2 + b];
+          const bool v = vy[a] && vx[b];
+          if (v && (m & 0xff) == k) acc.x += d[a * 2 + b].x;
+          if (v && ((m >> 8) & 0xff) == k) acc.y += d[a * 2 + b].y;
+          if (v && ((m >> 16) & 0xff) == k) acc.z += d[a * 2 + b].z;
+          if (v && (m >> 24) == k) acc.w += d[a * 2 + b].w;
+        }
+    } else {
     // windows oy with oy*stride - pad <= iy <= oy*stride - pad + 2
     const int oy_hi = min(OH - 1, (iy + pad) / stride);
     const int ox_hi = min(OW - 1, (ix + pad) / stride);
@@ -102,6 +131,7 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
         if (((am >> 16) & 0xff) == k) acc.z += d.z;
         if ((am >> 24) == k) acc.w += d.w;
       }
+    }
     }
     float4* o = reinterpret_cast<float4*>(din + ((size_t)(n * H + iy) * W + ix) * din_ld + g * 4);
     if (accumulate) {
