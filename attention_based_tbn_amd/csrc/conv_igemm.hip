@@ -759,6 +759,7 @@ int tbn_launch_conv(ConvP p, int rowmode, int mt, int nt, hipStream_t st) {
   const int full_M = p.N * p.OH * p.OW;
   static thread_local ConvPhases phases;   // ~2 KB kernel argument, built in place
   phases.n = 0;
+  bool empty_phase = false;
   for (int py = 0; py < 2; ++py)
     for (int px = 0; px < 2; ++px) {
       ConvP q = p;
@@ -799,12 +800,22 @@ int tbn_launch_conv(ConvP p, int rowmode, int mt, int nt, hipStream_t st) {
       q.M = p.N * q.OHs * q.OWs;
       q.alg_flops = flops_total * ((double)q.M / full_M);
       if (q.ntaps == 0) {
-        // no contributing tap (cannot happen for k >= 2): the gradient there is zero
+        // no contributing tap (1x1 stride-2 only): the gradient at this parity is zero
+        empty_phase = true;
         continue;
       }
       q.K = q.ntaps * p.Cin;
       phases.ph[phases.n++] = q;
     }
+  if (empty_phase && !(p.flags & CONV_FLAG_ACCUM)) {
+    // pixels no phase writes: clear the whole destination first (stream order keeps this ahead of the phases)
+    TBN_REQUIRE(p.nseg == 1, "conv: 1x1 strided data gradient writes one segment");
+    if (hipMemset2DAsync(p.seg[0].ptr, (size_t)p.seg[0].ld * sizeof(float), 0, (size_t)p.Cout * sizeof(float),
+                         (size_t)full_M, st) != hipSuccess) {
+      tbn_set_error("conv: hipMemset2DAsync failed");
+      return TBN_ERR_LAUNCH;
+    }
+  }
   if (phases.n == 0) return TBN_OK;
   // one tile shape for all phases (picked on the largest one), one launch
   int pmt = mt, pnt = nt;

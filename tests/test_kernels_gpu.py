@@ -121,6 +121,26 @@ def test_conv2d_fwd_dgrad_wgrad(case):
     assert relerr(dw.permute(0, 3, 1, 2), wr.grad) < TOL
 
 
+def _fuzz_cases(count, seed):
+    """seeded random conv geometries inside the kernels' documented domain (channels in multiples of 32, 1x1 / 3x3,
+    stride 1 / 2, any padding < k, ragged maps) -- none of them a BN-Inception layer shape"""
+    rng = np.random.RandomState(seed)
+    cases = []
+    while len(cases) < count:
+        k = int(rng.choice([1, 3]))
+        s = int(rng.choice([1, 2]))
+        p = int(rng.randint(0, k))
+        h, w = int(rng.randint(k, 23)), int(rng.randint(k, 23))
+        cin, cout = 32 * int(rng.randint(1, 12)), 32 * int(rng.randint(1, 12))
+        cases.append((int(rng.randint(1, 5)), h, w, cin, cout, k, s, p))
+    return cases
+
+
+@pytest.mark.parametrize("case", _fuzz_cases(48, 1234))
+def test_conv2d_fuzz(case):
+    test_conv2d_fwd_dgrad_wgrad(case)
+
+
 def test_wgrad_splitk_large_m():
     n, h, w, cin, cout, k, s, p = 8, 28, 28, 64, 64, 3, 1, 1
     x = torch.randn(n, cin, h, w, generator=g(1))
