@@ -189,6 +189,16 @@ def test_bn_relu_train_fwd_bwd(p_c):
     assert relerr(dg, gr.grad) < TOL and relerr(db, br.grad) < TOL
 
 
+def _bn_fuzz(count, seed):
+    rng = np.random.RandomState(seed)
+    return [(int(rng.randint(2, 3000)), 4 * int(rng.randint(1, 200))) for _ in range(count)]
+
+
+@pytest.mark.parametrize("p_c", _bn_fuzz(16, 77))
+def test_bn_fuzz(p_c):
+    test_bn_relu_train_fwd_bwd(p_c)
+
+
 @pytest.mark.parametrize("hw_s_p", [((15, 13), 2, 0), ((16, 16), 2, 0), ((7, 9), 1, 1), ((112, 3), 2, 0)])
 def test_maxpool_fwd_bwd(hw_s_p):
     (h, w), s, p = hw_s_p
@@ -215,6 +225,20 @@ def test_maxpool_fwd_bwd(hw_s_p):
     assert abs(float(dx.double().sum()) - float(dy.double().sum())) < 1e-3
     call("tbn_maxpool3_bwd", ptr(dyd), c, ptr(am), ptr(dx), c, n, h, w, c, oh, ow, s, p, 1, st())
     assert relerr(nchw(dx).cpu() * mask, 2 * xr.grad * mask) < 1e-6
+
+
+def _pool_fuzz(count, seed):
+    rng = np.random.RandomState(seed)
+    out = []
+    while len(out) < count:
+        s_, p_ = int(rng.choice([1, 2])), int(rng.choice([0, 1]))
+        out.append(((int(rng.randint(3, 40)), int(rng.randint(3, 40))), s_, p_))
+    return out
+
+
+@pytest.mark.parametrize("hw_s_p", _pool_fuzz(16, 99))
+def test_maxpool_fuzz(hw_s_p):
+    test_maxpool_fwd_bwd(hw_s_p)
 
 
 def test_avgpool_and_spatial_means():
@@ -264,6 +288,16 @@ def test_linear_fwd_bwd(mkn):
     y.backward(dy.to(DEV))
     assert relerr(y, yr.detach()) < TOL
     assert relerr(xd.grad, xr.grad) < TOL and relerr(wd.grad, wr.grad) < TOL and relerr(bd.grad, br.grad) < TOL
+
+
+def _linear_fuzz(count, seed):
+    rng = np.random.RandomState(seed)
+    return [(int(rng.randint(1, 300)), int(rng.randint(1, 1200)), int(rng.randint(1, 600))) for _ in range(count)]
+
+
+@pytest.mark.parametrize("mkn", _linear_fuzz(16, 5))
+def test_linear_fuzz(mkn):
+    test_linear_fwd_bwd(mkn)
 
 
 def test_linear_pads_odd_sizes():
