@@ -5,9 +5,10 @@ parameter broadcast + scatter/gather + reduce to GPU 0).  Here every rank holds 
 the full forward/backward on its own shard of the clips (per-replica BatchNorm statistics, as
 nn.DataParallel's chunks had) and gradients are averaged with one collective per LARGE parameter
 tensor -- the backbones keep their parameters in a few flat tensors (~41 MB per backbone) -- plus ONE
-for all small tensors (heads, biases, BN affine) packed into a flat buffer: four all-reduces per step,
-issued on RCCL's stream at the end of backward (when the engine has joined the per-backbone side
-streams).  No collective on the data path.
+for all small tensors (heads, biases, BN affine) packed into a flat buffer: four all-reduces per step.
+A backbone's all-reduce is issued as soon as autograd has accumulated its flat gradient, i.e. while the
+backbones whose backward was enqueued later are still running on their own HIP streams; the packed
+small-tensor collective goes last.  No collective on the data path.
 
 `DataParallel(model)` keeps the reference surface: `.module`, `forward`, `get_loss(...)`,
 `state_dict()` of the wrapped model under the `module.` prefix.
@@ -18,11 +19,12 @@ import torch.nn as nn
 
 
 class DataParallel(nn.Module):
-    def __init__(self, module, device_ids=None, process_group=None, broadcast_parameters=True):
+    def __init__(self, module, device_ids=None, process_group=None, broadcast_parameters=True, overlap=True):
         super().__init__()
         self.module = module
         self.device_ids = device_ids
         self.process_group = process_group
+        self.overlap = overlap          # False: every collective at the end of backward (diagnostic)
         self._pending = []
         self._ready = []
         self._callback_queued = False
@@ -41,15 +43,23 @@ class DataParallel(nn.Module):
             for t in list(self.module.parameters()) + list(self.module.buffers()):
                 dist.broadcast(t, src, group=self.process_group)
 
-    def _on_grad_ready(self, p):
-        """post-accumulate-grad hook: remember the tensor, arrange ONE callback at the end of backward.
+    def _reduce_op(self):
+        avg = dist.get_backend(self.process_group) == "nccl"
+        return avg, (dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM)
 
-        The collectives are issued from that callback, not from here: the backbones run their backward
-        on side HIP streams, and the autograd engine only guarantees that the caller's current stream
-        has waited for every leaf stream once backward is complete (it syncs them right before the
-        final callbacks run).  Issuing there is correct by construction; the all-reduces of the few flat
-        tensors (3 x ~41 MB + heads) then run back to back on RCCL's stream."""
-        self._ready.append(p)
+    def _on_grad_ready(self, p):
+        """post-accumulate-grad hook.  A large (flat backbone) gradient is all-reduced right here: the hook
+        runs inside the AccumulateGrad node, whose stream the autograd engine has already made wait for the
+        producing backbone's side stream (the stream semantics torch's own DDP reducer relies on), and the
+        process group orders its collective after the current stream -- so the transfer starts when THAT
+        backbone's backward has finished on the GPU, under the backward of the others.  Hooks fire in the
+        same (reverse-forward) order on every rank, so the collectives match up.  Small tensors are only
+        remembered; one callback at the end of backward packs and reduces them and waits for everything."""
+        if self.overlap and p.grad is not None and p.grad.numel() >= self.SMALL:
+            _, op = self._reduce_op()
+            self._pending.append((p.grad, dist.all_reduce(p.grad, op=op, group=self.process_group, async_op=True)))
+        else:
+            self._ready.append(p)
         if not self._callback_queued:
             self._callback_queued = True
             torch.autograd.Variable._execution_engine.queue_callback(self.finish_gradient_sync)
@@ -58,13 +68,15 @@ class DataParallel(nn.Module):
 
     def finish_gradient_sync(self):
         """average every gradient produced by this backward across ranks (RCCL all-reduce): one collective per
-        large (flat backbone) tensor, ONE for all the small head / bias / BN tensors together"""
-        avg = dist.get_backend(self.process_group) == "nccl"
-        op = dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM
+        large (flat backbone) tensor -- already in flight when `overlap` -- and ONE for all the small head /
+        bias / BN tensors together"""
+        avg, op = self._reduce_op()
         grads = [p.grad for p in self._ready if p.grad is not None]
         small = [g for g in grads if g.numel() < self.SMALL]
         large = [g for g in grads if g.numel() >= self.SMALL]
-        works = [dist.all_reduce(g, op=op, group=self.process_group, async_op=True) for g in large]
+        works = [w for _, w in self._pending]
+        works += [dist.all_reduce(g, op=op, group=self.process_group, async_op=True) for g in large]
+        large = [g for g, _ in self._pending] + large
         flat = None
         if small:
             flat = torch.cat([g.reshape(-1) for g in small])

@@ -43,14 +43,14 @@ def run(m):
     model.module.load_state_dict(st)                      # undo the BN running-stat update
     return {k: p.grad.clone() for k, p in model.module.named_parameters() if p.grad is not None}
 local = run(model.module)                                 # no collective
-synced = run(model)                                       # hooks + all-reduce at the end of backward
+synced = run(model)                                       # hooks: backbone all-reduces inside backward, small tensors at its end
 for k, gl in local.items():
     parts = [torch.empty_like(gl) for _ in range(2)]
     dist.all_gather(parts, gl)
     want = (parts[0] + parts[1]) / 2
     err = float((synced[k] - want).abs().max() / (want.abs().max() + 1e-20))
     assert err < 1e-5, (k, err)
-assert len(local) >= 12 and model._ready == []
+assert len(local) >= 12 and model._ready == [] and model._pending == []
 print("DP_GPU_OK", rank, len(local))
 '''
 

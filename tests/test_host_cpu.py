@@ -154,7 +154,8 @@ class Toy(nn.Module):
         self.register_buffer("stat", torch.full((3,), float(rank)))
     def forward(self, x): return self.b(torch.relu(self.a(x)))
     def get_loss(self, criterion, target, preds, epoch=0): return {"total": criterion(preds, target)}, preds.shape[0]
-model = DataParallel(Toy())
+DataParallel.SMALL = 16                             # a.weight (32 elements) takes the "large tensor" route
+model = DataParallel(Toy(), overlap=os.environ["DP_OVERLAP"] == "1")
 ref = Toy(); ref.load_state_dict(model.module.state_dict())
 assert float(model.module.stat[0]) == 0.0          # buffers came from rank 0
 g = torch.Generator().manual_seed(7)
@@ -165,13 +166,14 @@ loss["total"].backward()
 nn.MSELoss()(ref(X), Y).backward()                  # full-batch reference on every rank
 for (n, p), (_, q) in zip(model.module.named_parameters(), ref.named_parameters()):
     assert torch.allclose(p.grad, q.grad, atol=1e-6), n
-assert model._pending == [] and bs == 4
+assert model._pending == [] and model._ready == [] and bs == 4
 sd = model.state_dict(); assert all(k.startswith("module.") for k in sd)
 print("DP_OK", rank)
 '''
 
 
-def test_dataparallel_gradient_average_gloo_world2(tmp_path):
+@pytest.mark.parametrize("overlap", [True, False])
+def test_dataparallel_gradient_average_gloo_world2(tmp_path, overlap):
     script = tmp_path / "dp_worker.py"
     script.write_text(_DP_WORKER)
     with socket.socket() as s:
@@ -180,7 +182,7 @@ def test_dataparallel_gradient_average_gloo_world2(tmp_path):
     procs = []
     for r in range(2):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   OMP_NUM_THREADS="1")
+                   OMP_NUM_THREADS="1", DP_OVERLAP=str(int(overlap)))
         procs.append(subprocess.Popen([sys.executable, str(script), ROOT], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.STDOUT, text=True))
     outs = [p.communicate(timeout=240)[0] for p in procs]
