@@ -88,7 +88,8 @@ def test_train_forward_loss_grads(name):
         for k, v in out.items():
             assert rel_err(v, data[f"ep{ep}_out_{k}"]) < TOL, k
         for k, v in loss.items():
-            assert abs(float(v) - float(data[f"ep{ep}_loss_{k}"])) < 1e-5 * max(1, abs(float(v))), (ep, k)
+            v = float(v.detach()) if torch.is_tensor(v) else float(v)
+            assert abs(v - float(data[f"ep{ep}_loss_{k}"])) < 1e-5 * max(1, abs(v)), (ep, k)
         params = dict(model.named_parameters())
         n_checked = 0
         for k in data:

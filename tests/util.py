@@ -40,6 +40,6 @@ def build_oracle(cfg, modality, meta):
 
 
 def rel_err(a, b):
-    a = torch.as_tensor(a).double()
-    b = torch.as_tensor(b).double()
+    a = torch.as_tensor(a).detach().double()
+    b = torch.as_tensor(b).detach().double()
     return float((a - b).abs().max() / (b.abs().max() + 1e-30))
