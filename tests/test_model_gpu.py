@@ -270,6 +270,57 @@ def test_full_size_properties_config4_shapes():
     assert model.Base_RGB.bn_weight_rest.grad is None and model.Base_RGB.bn_weight_first.grad is not None
 
 
+@pytest.mark.parametrize("ov,sizes", [
+    (["model.attention.enable=False", "data.audio.audio_length=1.279", "data.sampling=async",
+      "model.fusion_dropout=0"], {"RGB": (3, 224, 224), "Flow": (10, 224, 224), "Audio": (1, 256, 256)}),
+    (["data.flow.enable=False", "model.attention.use_entropy=True", "model.fusion_dropout=0",
+      "model.attention.attn_dropout=0.0"], {"RGB": (3, 224, 224), "Audio": (1, 256, 420)}),
+])
+def test_full_size_train_and_eval_vs_oracle(ov, sizes):
+    """the whole path at BASELINE.json's full input sizes (config 4: three modalities, 1.279 s audio; config 3 as the
+    reference README runs it: RGB + 2.1 s audio = 256x420 spectrogram, T = 13, MHA + entropy loss) against the CPU
+    oracle carrying the same weights: training-mode logits / attention weights / losses (batch-stat BN, dropout off),
+    the BN running statistics after the step, then eval logits.  1e-3 relative, the north star's tolerance."""
+    from attention_based_tbn_amd.config import load_config, get_modality
+    cfg = load_config(ov)
+    modality = get_modality(cfg)
+    from attention_based_tbn_amd.core.models import build_model
+    probe, _, _ = build_model(cfg, modality, DEV)
+    meta = {"keys": [[k, list(v.shape)] for k, v in probe.state_dict().items()], "fill_seed": 11}
+    del probe
+    model, crit = build_product(cfg, modality, meta)
+    oracle, ocrit = build_oracle(cfg, modality, meta)
+    g = torch.Generator().manual_seed(5)
+    B, n = 2, 3
+    inp = {m: (torch.randn(B, n, *sizes[m], generator=g) * 3 - 6) if m == "Audio"
+           else (torch.rand(B, n, *sizes[m], generator=g) - 0.45) for m in modality}
+    target = {"class": {"verb": torch.randint(0, 125, (B,), generator=g), "noun": torch.randint(0, 352, (B,), generator=g)}}
+    model.train()
+    oracle.train()
+    out = model(to_dev(inp))
+    want = oracle(inp)
+    assert set(out) == set(want)
+    for k in want:
+        assert rel_err(out[k].detach().cpu(), want[k].detach()) < 1e-3, (k, rel_err(out[k].detach().cpu(), want[k].detach()))
+    for ep in (0, 20):
+        loss, bs = model.get_loss(crit, {"class": to_dev(target["class"])}, out, epoch=ep)
+        wl, wbs = oracle.get_loss(ocrit, target, want, epoch=ep)
+        assert bs == wbs and set(loss) == set(wl)
+        for k in wl:
+            a, b = float(torch.as_tensor(loss[k]).detach()), float(torch.as_tensor(wl[k]).detach())
+            assert abs(a - b) < 1e-3 * max(1.0, abs(b)), (ep, k)
+    st, wst = model.state_dict(), oracle.state_dict()
+    for k in wst:
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            assert rel_err(st[k].cpu(), wst[k]) < 1e-3, k
+    model.eval()
+    oracle.eval()
+    with torch.no_grad():
+        out, want = model(to_dev(inp)), oracle(inp)
+    for k in want:
+        assert rel_err(out[k].cpu(), want[k]) < 1e-3, (k, rel_err(out[k].cpu(), want[k]))
+
+
 def test_state_dict_roundtrip_with_oracle_checkpoint():
     """a reference-format checkpoint (here: the oracle's state_dict) loads and round-trips"""
     cfg, modality, meta, data, inp, target = load_case("cfg5_all_mha_eval")
