@@ -144,17 +144,30 @@ def main():
     args = ap.parse_args()
     # stdout carries exactly ONE line (the JSON result, rank 0): everything the model code prints while it builds
     # (the reference's "Freezing the batchnorms ..." notices, on every rank) goes to stderr
-    json_out, sys.stdout = sys.stdout, sys.stderr
+    # -- C libraries included (RCCL / gloo log to file descriptor 1): fd 1 is pointed at stderr for the run and the
+    # JSON line is written to a duplicate of the original stdout
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+    sys.stdout = sys.stderr
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback)"
+    if os.environ.get("TBN_BENCH_BACKEND", "nccl") != "nccl":
+        local_rank = local_rank % torch.cuda.device_count()      # rehearsal: ranks share the card(s) present
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        # RCCL ("nccl") is the product backend; TBN_BENCH_BACKEND=gloo only exists to rehearse the N > 1 control flow
+        # with several ranks sharing ONE GPU (RCCL needs a GPU per rank) -- never a measurement
+        backend = os.environ.get("TBN_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
 
     from attention_based_tbn_amd.config import load_config, get_modality
