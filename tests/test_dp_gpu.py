@@ -70,3 +70,24 @@ def test_dataparallel_real_model_two_ranks_on_one_gpu(tmp_path):
     outs = [p.communicate(timeout=600)[0] for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and f"DP_GPU_OK {r}" in o, o[-3000:]
+
+
+def test_bench_n2_control_flow_rehearsal():
+    """`bench.py --gpus 2` exactly as the driver launches it (torch.distributed.run, one rank per process), with the
+    two ranks sharing the one card over gloo (TBN_BENCH_BACKEND=gloo: RCCL needs a GPU per rank): the barrier /
+    max-over-ranks timing / DataParallel path must run and stdout must be exactly one JSON line from rank 0."""
+    import json
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, TBN_BENCH_BACKEND="gloo", OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
+           "--warmup", "1", "--batch-per-gpu", "2"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["config"]["global_batch"] == 4 and d["value"] > 0
+    assert d["scaling"] == "weak" and "cpu_baseline" not in d and d["roofline"]["frac"] > 0
