@@ -21,6 +21,7 @@
 // ROWMODE is the 7x7 stem: input is NHWC padded to `cp` channels, a filter row (7*cp floats,
 //   padded to a multiple of 32) is one contiguous K run.
 #include <cstdio>
+#include <cstdlib>
 #include <type_traits>
 
 #include "tbn_common.h"
@@ -33,6 +34,7 @@
 #define TBN_ABLATE 0
 #endif
 #define ABL(bit) (TBN_ABLATE && (p.flags & (bit)))
+#define WABL(bit) (TBN_ABLATE && (p.ablate & (bit)))   // weight-gradient kernel: 1 no loop loads, 2 no LDS stores, 4 no MFMA
 
 // Hardware-bounds-checked 16-B loads.  ROCm 7.2's clang lowers __builtin_amdgcn_raw_buffer_load_b128 to a
 // ONE-dword load, so the LLVM intrinsic is bound directly (same idiom as composable_kernel).
@@ -505,9 +507,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
   const int lrow = lane & 31, lhalf = lane >> 5;
   load_tiles(pbeg + wave * KR);
   for (int it = 0; it < nsteps; ++it) {
-    store_tiles();
+    if (!WABL(2) || it == 0) store_tiles();
     __builtin_amdgcn_wave_barrier();
-    if (it + 1 < nsteps) load_tiles(pbeg + ((it + 1) * 4 + wave) * KR);
+    if (it + 1 < nsteps && !WABL(1)) load_tiles(pbeg + ((it + 1) * 4 + wave) * KR);
+    if (WABL(4)) continue;
     // Fragments of k-pair kp+1 are read while k-pair kp multiplies (two register sets; the sched_group_barrier
     // chain pins the DS-read group / MFMA group alternation).  Consecutive MFMAs rotate over FOUR independent
     // accumulators: a dependent MFMA is only free right behind its producer or >= 4 MFMAs later -- alternating
@@ -863,20 +866,44 @@ static void launch_wgrad(const WgradP& p, int blocks, hipStream_t st) {
 // extent is a multiple of 64 or large, else 1
 static int pick_wtile(int c) { return (c % 96 == 0 && c % 64 != 0) ? 3 : ((c % 64 == 0 || c > 96) ? 2 : 1); }
 
-// plan: tile (0 = heuristic) + split-K so that the grid has >= ~3 workgroups per CU and every split >= 256 rows
+// plan: tile (0 = heuristic) + split-K.  The kernel's register budget admits `occ` workgroups per CU, so a grid runs
+// in rounds of 256 * occ workgroups and a partly filled last round costs a full one: for every round count R = 1..8
+// take the largest split count that still fits R rounds and keep the cheapest by
+//   rounds * (K-steps per workgroup + 1) * step time  +  split-K reduce traffic
+// (fitted to a sweep of 12 layer shapes x 24 plans, scripts/wgrad_ablate.py SWEEP=1: within 2 % of the best measured
+// plan per layer, 11 % below the former "about 768 workgroups" rule on one stream).  Every split keeps >= 256 rows.
 void tbn_wgrad_plan(int M, int Cout, int Cin, int taps, int* mt, int* nt, int* splits, int* rows_per_split) {
   if (*mt < 1 || *mt > 3) *mt = pick_wtile(Cout);
   if (*nt < 1 || *nt > 3) *nt = pick_wtile(Cin);
   const int tiles = cdiv(Cout, 32 * *mt) * cdiv(Cin, 32 * *nt) * taps;
-  int want = cdiv(768, tiles);
-  int max_splits = cdiv(M, 256);
-  int s = want < 1 ? 1 : want;
-  if (s > max_splits) s = max_splits;
-  if (s < 1) s = 1;
-  int rps = cdiv(cdiv(M, s), 64) * 64;
-  s = cdiv(M, rps);
-  *splits = s;
-  *rows_per_split = rps;
+  const int max_splits = cdiv(M, 256);
+  auto settle = [&](int s, int* rps) {
+    if (s > max_splits) s = max_splits;
+    if (s < 1) s = 1;
+    *rps = cdiv(cdiv(M, s), 64) * 64;
+    return cdiv(M, *rps);
+  };
+#if TBN_ABLATE
+  if (const char* e = getenv("TBN_WGRAD_TARGET")) {   // scripts/wgrad_ablate.py: fixed grid target
+    *splits = settle(cdiv(atoi(e), tiles), rows_per_split);
+    return;
+  }
+#endif
+  const int occ = (*mt == 3 || *nt == 3) ? 1 : 2;           // 248+144 / 184+96 registers vs 128+64
+  const int slots = 256 * occ;
+  const double step_us = *mt * *nt * 8 * 64 / 2.4e3 * occ;  // 8 k-pairs x MT*NT MFMAs of 64 cycles, SIMD shared by occ waves
+  const double slab_mb = (double)Cout * Cin * taps * 4e-6;
+  double best = 0.0;
+  for (int R = 1; R <= 8; ++R) {
+    int rps;
+    const int s = settle(R * slots / tiles, &rps);
+    const double cost = cdiv(tiles * s, slots) * (rps / 64 + 1) * step_us + (s > 1 ? 0.3 * s * slab_mb : 0.0);
+    if (R == 1 || cost < best) {
+      best = cost;
+      *splits = s;
+      *rows_per_split = rps;
+    }
+  }
 }
 
 // split-K slab floats: the worst case over every tile the autotuner may choose
@@ -903,6 +930,9 @@ int tbn_launch_wgrad(WgradP p, int rowmode, float* dw, float* workspace, hipStre
     p.x_bytes = (unsigned)xb;
     p.dy_bytes = (unsigned)db;
   }
+#if TBN_ABLATE
+  if (const char* e = getenv("TBN_WGRAD_ABLATE")) p.ablate = atoi(e);
+#endif
   int mt = p.mt, nt = p.nt, splits, rps;   // 0: heuristic tile
   tbn_wgrad_plan(p.M, p.Cout, p.Cin, p.taps, &mt, &nt, &splits, &rps);
   p.K = p.taps * p.Cin;

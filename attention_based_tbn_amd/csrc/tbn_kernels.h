@@ -59,6 +59,7 @@ struct WgradP {
   FastDiv div_ohw, div_ow;
   double alg_flops;       // host only
   unsigned dy_bytes, x_bytes;
+  int ablate;             // timing ablations, honoured by -DTBN_ABLATE=1 builds only (scripts/wgrad_ablate.py)
 };
 
 // optional in-process profiler: brackets every conv-GEMM launch with hipEvents on its stream
