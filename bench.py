@@ -138,6 +138,9 @@ def main():
     ap.add_argument("--no-multi-stream", action="store_true", help="diagnostic: run the modality backbones on one stream")
     ap.add_argument("--no-aux-stream", action="store_true", help="diagnostic: weight gradients on the backbone's own stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--host-inputs", action="store_true",
+                    help="diagnostic (never the headline): the batch starts in pinned HOST memory every step and is copied "
+                         "over PCIe on a side stream, double-buffered against the previous step -- the PCIe-inclusive rate")
     ap.add_argument("--profile-every", type=int, default=1 << 30,
                     help="bracket conv-GEMM launches with HIP events on every k-th timed step (default: the first "
                          "timed step only; 0 = never).  Profiled steps run single-stream, see DESIGN.md")
@@ -210,7 +213,27 @@ def main():
             loss, _ = model.get_loss(criterion, tgt, out, 0)
         return loss["total"]
 
+    host_inp, copy_stream, staged = None, None, [None]
+    if args.host_inputs:
+        host_inp = {k: v.cpu().pin_memory() for k, v in inp.items()}
+        copy_stream = torch.cuda.Stream(device=device)
+
+        def stage():          # H2D of the NEXT batch on the copy stream, overlapping the current step
+            with torch.cuda.stream(copy_stream):
+                bufs = {k: v.to(device, non_blocking=True) for k, v in host_inp.items()}
+                ev = torch.cuda.Event()
+                ev.record(copy_stream)
+            staged[0] = (bufs, ev)
+        stage()
+
     def step():
+        if host_inp is not None:
+            bufs, ev = staged[0]
+            torch.cuda.current_stream().wait_event(ev)
+            for k in bufs:
+                bufs[k].record_stream(torch.cuda.current_stream())
+            inp.update(bufs)
+            stage()
         if not C_["train"]:
             return eval_step()
         if args.forward_only:
@@ -293,7 +316,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": C_["name"] + (" [forward only]" if args.forward_only and C_["train"] else ""),
                        "batch_per_gpu": B, "global_batch": B * world, "segments": n,
-                       "parallelism": f"dp{world}" if world > 1 else "single"},
+                       "parallelism": f"dp{world}" if world > 1 else "single",
+                       **({"inputs": "pinned host memory, PCIe copy every step (diagnostic)"} if args.host_inputs else {})},
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline and args.config == 4 and not args.forward_only:
