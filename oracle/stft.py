@@ -12,7 +12,9 @@ window="hann", center=True, pad_mode="constant")` is restated:
   * X = rfft(window * frame) in float64 (256 bins), stored as complex64;
 then the reference takes log(real(X*conj(X)) + 1e-6) in float32.
 PARITY UNPINNED against librosa itself (not installable offline); pinned by the
-known-answer tests in tests/test_stft_oracle.py (pure tone, Parseval, shapes).
+known-answer tests in tests/test_stft_oracle.py (pure tone, Parseval, shapes) and
+cross-checked there against scipy.signal.stft, an independent implementation of
+the same framing (zero boundary extension by n_fft // 2, hop 120, no end padding).
 """
 import numpy as np
 

@@ -91,3 +91,24 @@ def test_log_mel_spectrogram_known_answers():
     # doubling the amplitude leaves a max-referenced dB map unchanged
     db2 = log_mel_spectrogram((2 * np.sin(2 * np.pi * f0 * t)).astype(np.float32))
     assert np.abs(db2 - db)[db > -70].max() < 1e-3
+
+
+def test_restatement_agrees_with_scipy_stft():
+    """independent implementation of the same framing: scipy.signal.stft with the 511-sample centrally padded periodic
+    Hann window (scipy.signal.get_window("hann", 240, fftbins=True) is what librosa 0.7.2 itself calls), hop 120,
+    zero boundary extension of n_fft // 2 -- librosa.stft's centre=True / pad_mode="constant" -- and no end padding"""
+    import scipy.signal as ss
+    rng = np.random.RandomState(3)
+    for L in (30695, 30720, 50400, 1000):
+        y = (0.1 * rng.randn(L)).astype(np.float32)
+        w = np.zeros(511)
+        w[135:375] = ss.get_window("hann", 240, fftbins=True)
+        assert np.allclose(w, stft_window(), rtol=0, atol=1e-15)
+        _, _, Z = ss.stft(y.astype(np.float64), window=w, nperseg=511, noverlap=511 - 120, nfft=511, boundary="zeros",
+                          padded=False, return_onesided=True)
+        Z = Z * w.sum()                                   # scipy normalises by the window sum
+        S = stft_complex(y)
+        assert S.shape == Z.shape == (256, 1 + (L - 1) // 120)
+        assert np.abs(S - Z).max() < 1e-5 * np.abs(Z).max()
+        ref = np.log((Z * np.conj(Z)).real + 1e-6).astype(np.float32)
+        assert np.abs(log_power_spectrogram(y) - ref).max() < 2e-4      # complex64 storage in the restatement
