@@ -66,6 +66,22 @@ def test_restated_cv2_linear_resize_known_answers():
     assert out.dtype == np.uint8 and out.shape == (224, 224, 3)
 
 
+def test_restated_cv2_resize_agrees_with_float_bilinear():
+    """independent check of the sampling geometry: cv2's INTER_LINEAR is half-pixel-centred bilinear without
+    antialiasing -- torch's `interpolate(mode="bilinear", align_corners=False, antialias=False)` -- evaluated in
+    11-bit fixed point; the 8-bit results must sit within one grey level of the float evaluation, up- and down-scaling"""
+    import torch
+    import torch.nn.functional as F
+    rng = np.random.RandomState(5)
+    for (h, w), (nh, nw) in (((256, 456), (224, 399)), ((120, 160), (256, 341)), ((37, 53), (224, 224)), ((300, 200), (75, 50))):
+        img = rng.randint(0, 256, (h, w, 3)).astype(np.uint8)
+        got = otf.resize_linear_u8(img, nw, nh).astype(np.float64)
+        ref = F.interpolate(torch.from_numpy(img).permute(2, 0, 1)[None].double(), size=(nh, nw), mode="bilinear",
+                            align_corners=False, antialias=False)[0].permute(1, 2, 0).numpy()
+        assert np.abs(got - ref).max() <= 1.0, ((h, w), (nh, nw), np.abs(got - ref).max())
+        assert abs((got - ref).mean()) < 0.25          # the truncating shifts of the fixed-point form bias by ~0.1 level
+
+
 def test_host_draw_order_matches_reference_sampler():
     """the recorded geometry of the device pipeline consumes the NumPy RNG exactly like the oracle / reference"""
     from attention_based_tbn_amd.core.dataset.transform import MultiScaleCrop, RandomHorizontalFlip, _Geometry
