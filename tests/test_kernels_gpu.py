@@ -29,7 +29,7 @@ def nchw(x):
 
 
 def relerr(a, b):
-    a, b = a.double().cpu(), b.double().cpu()
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
     return float((a - b).abs().max() / (b.abs().max() + 1e-30))
 
 
