@@ -126,7 +126,7 @@ def cpu_baseline(seconds_budget=25.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", type=int, default=4, choices=sorted(CONFIGS),
                     help="BASELINE.json config (4 = the headline metric; 2, 3, 5 are the other single-GPU-sized configs)")
