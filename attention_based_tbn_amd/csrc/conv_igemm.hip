@@ -874,7 +874,13 @@ static int pick_wtile(int c) { return (c % 96 == 0 && c % 64 != 0) ? 3 : ((c % 6
 // plan per layer, 11 % below the former "about 768 workgroups" rule on one stream).  Every split keeps >= 256 rows.
 void tbn_wgrad_plan(int M, int Cout, int Cin, int taps, int* mt, int* nt, int* splits, int* rows_per_split) {
   if (*mt < 1 || *mt > 3) *mt = pick_wtile(Cout);
-  if (*nt < 1 || *nt > 3) *nt = pick_wtile(Cin);
+  if (*nt < 1 || *nt > 3) {
+    *nt = pick_wtile(Cin);
+    // 160 / 224 input channels: 64-wide tiles would multiply 20 / 14 % zero columns; 32-wide ones measured 5-22 %
+    // faster there (profiles/r01_wgrad_tiles.txt).  The Cout side keeps its 64-wide tiles (narrow ones lose more
+    // than the padding costs).
+    if (*nt == 2 && Cin % 64 != 0 && cdiv(Cin, 64) * 64 * 100 >= Cin * 112) *nt = 1;
+  }
   const int tiles = cdiv(Cout, 32 * *mt) * cdiv(Cin, 32 * *nt) * taps;
   const int max_splits = cdiv(M, 256);
   auto settle = [&](int s, int* rps) {
@@ -932,6 +938,8 @@ int tbn_launch_wgrad(WgradP p, int rowmode, float* dw, float* workspace, hipStre
   }
 #if TBN_ABLATE
   if (const char* e = getenv("TBN_WGRAD_ABLATE")) p.ablate = atoi(e);
+  if (const char* e = getenv("TBN_WGRAD_MT")) p.mt = atoi(e);
+  if (const char* e = getenv("TBN_WGRAD_NT")) p.nt = atoi(e);
 #endif
   int mt = p.mt, nt = p.nt, splits, rps;   // 0: heuristic tile
   tbn_wgrad_plan(p.M, p.Cout, p.Cin, p.taps, &mt, &nt, &splits, &rps);

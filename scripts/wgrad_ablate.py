@@ -23,6 +23,13 @@ def run(flags, reps=10):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps * 1e3
 print(f"shape {sys.argv[1:9]}  ideal {flops/157.3e12*1e6:.1f} us (incl. split-K reduce launch in every column)")
+if os.environ.get("TILES"):          # weight-gradient time per forced tile (0,0 = the heuristic)
+    ws = torch.empty(max(1, lib().tbn_conv2d_wgrad_workspace_floats(n, h, w, cin, cout, k, s, p)) * 4, device=DEV)
+    for mt, nt in [(0, 0), (1, 1), (1, 2), (2, 1), (2, 2), (1, 3), (3, 1), (2, 3), (3, 2), (3, 3)]:
+        os.environ["TBN_WGRAD_MT"], os.environ["TBN_WGRAD_NT"] = str(mt), str(nt)
+        t = run(0)
+        print(f"tile <{mt},{nt}>  {t:8.1f} us  {flops / t / 1e6:6.1f} TF/s")
+    sys.exit(0)
 if os.environ.get("SWEEP"):
     ws = torch.empty(max(1, lib().tbn_conv2d_wgrad_workspace_floats(n, h, w, cin, cout, k, s, p)) * 16, device=DEV)
     print("target\\minrows " + " ".join(f"{m:8d}" for m in (256, 640, 1280, 2560)))
