@@ -50,7 +50,7 @@ def test_eval_forward_matches_reference_golden(name):
         loss, bs = model.get_loss(crit, tgt, out, epoch=ep)
         for k, v in loss.items():
             want = float(data[f"loss_ep{ep}_{k}"])
-            assert abs(float(v) - want) < 1e-3 * max(1.0, abs(want)), (ep, k)
+            assert abs(float(torch.as_tensor(v).detach()) - want) < 1e-3 * max(1.0, abs(want)), (ep, k)
 
 
 @pytest.mark.parametrize("name", TRAIN_CASES)
@@ -73,7 +73,7 @@ def test_train_step_matches_reference_golden(name):
             assert rel_err(v.detach().cpu(), data[f"ep{ep}_out_{k}"]) < 1e-3, (ep, k)
         for k, v in loss.items():
             want = float(data[f"ep{ep}_loss_{k}"])
-            assert abs(float(v) - want) < 1e-3 * max(1.0, abs(want)), (ep, k)
+            assert abs(float(torch.as_tensor(v).detach()) - want) < 1e-3 * max(1.0, abs(want)), (ep, k)
         grads = reference_named_grads(model)
         truth = fp64_truth(cfg, modality, meta, inp, target, tgt, ep)
         checked = 0
