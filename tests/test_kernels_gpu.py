@@ -156,6 +156,28 @@ def test_wgrad_splitk_large_m():
     assert relerr(dw.permute(0, 3, 1, 2), wr.grad) < TOL
 
 
+def test_wgrad_many_splitk_slabs_deterministic():
+    """a stem-sized reduction (M = 50 176 pixel rows, 54 tiles): the round-quantisation plan cuts it into dozens of
+    split-K slabs; the slab reduce must be exact to fp32 accumulation error and bit-reproducible run to run"""
+    n, h, w, cin, cout, k, s, p = 16, 56, 56, 64, 96, 3, 1, 1
+    x = torch.randn(n, cin, h, w, generator=g(1))
+    dy = torch.randn(n, cout, h, w, generator=g(2))
+    wr = torch.zeros(cout, cin, k, k, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.double(), wr, None, stride=s, padding=p).backward(dy.double())
+    nws = lib().tbn_conv2d_wgrad_workspace_floats(n, h, w, cin, cout, k, s, p)
+    assert nws >= 16 * cout * k * k * cin          # at least 16 slabs
+    ws = torch.empty(nws, device=DEV)
+    dyd, xd = nhwc(dy).to(DEV), nhwc(x).to(DEV)
+    outs = []
+    for _ in range(2):
+        dw = torch.empty(cout, k, k, cin, device=DEV)
+        ws.fill_(float("nan"))                      # stale workspace contents must not leak into the result
+        call("tbn_conv2d_wgrad", ptr(dyd), cout, ptr(xd), cin, ptr(dw), n, h, w, cin, cout, k, s, p, ptr(ws), st())
+        outs.append(dw)
+    assert torch.equal(outs[0], outs[1])
+    assert relerr(outs[0].permute(0, 3, 1, 2), wr.grad) < TOL
+
+
 @pytest.mark.parametrize("p_c", [(2 * 14 * 14, 96), (3 * 7 * 5, 384), (1000, 32), (48, 704), (48, 128), (192, 192),
                                  (5000, 736)])
 def test_bn_relu_train_fwd_bwd(p_c):
