@@ -25,6 +25,10 @@ for i in ids:
     for k, v in e.items():
         if isinstance(v, (int, float)) and k not in ("grid",): a[k] += v
 names = sorted({k for a in agg.values() for k in a} - {"n", "t"})
-print("kernel vgpr agpr lds | n us " + " ".join(names))
+# MFMA pipe utilisation: SQ_VALU_MFMA_BUSY_CYCLES sums the busy cycles of all 1024 SIMDs (= 64 cycles per
+# v_mfma_f32_32x32x2_f32, checked against SQ_INSTS_MFMA); GRBM_GUI_ACTIVE sums the active cycles of the 8 XCDs
+util = "SQ_VALU_MFMA_BUSY_CYCLES" in names and "GRBM_GUI_ACTIVE" in names
+print("kernel vgpr agpr lds | n us " + " ".join(names) + (" | MFMA_busy_%" if util else ""))
 for key, a in sorted(agg.items(), key=lambda kv: -kv[1]["t"])[:int(sys.argv[2]) if len(sys.argv) > 2 else 30]:
-    print(f"{key[0][:44]:44s} v{key[1]:>3s} a{key[2]:>3s} l{key[3]:>6s} | {int(a['n']):4d} {a['t']/1e3:9.1f} " + " ".join(f"{a[k]:.4g}" for k in names))
+    extra = f" | {100.0 * a['SQ_VALU_MFMA_BUSY_CYCLES'] / (a['GRBM_GUI_ACTIVE'] / 8 * 1024):5.1f}" if util and a["GRBM_GUI_ACTIVE"] else ""
+    print(f"{key[0][:44]:44s} v{key[1]:>3s} a{key[2]:>3s} l{key[3]:>6s} | {int(a['n']):4d} {a['t']/1e3:9.1f} " + " ".join(f"{a[k]:.4g}" for k in names) + extra)
