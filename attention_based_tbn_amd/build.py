@@ -30,8 +30,18 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+STAMP = os.path.join(CSRC, ".build_flags")   # the flag set the objects were built with (diagnostic -D switches included)
+
+
 def build(force=False, verbose=True):
     hipcc = _hipcc()
+    flagset = " ".join(FLAGS)
+    try:
+        with open(STAMP) as f:
+            if f.read() != flagset:
+                force = True         # e.g. a TBN_DIAG / TBN_ABLATE build before: never link those objects into a plain build
+    except OSError:
+        force = force or any(os.path.exists(os.path.join(CSRC, s.replace(".hip", ".o"))) for s in SOURCES)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.join(os.path.dirname(HERE), "include", "tbn_hip.h"))
     objs, jobs = [], []
@@ -53,6 +63,8 @@ def build(force=False, verbose=True):
 
     with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
         list(ex.map(run, jobs))
+    with open(STAMP, "w") as f:
+        f.write(flagset)
     if jobs or force or _stale(LIB, objs):
         run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
     return LIB

@@ -114,11 +114,18 @@ class _BackboneFn(torch.autograd.Function):
             ctx.plan, ctx.ws, ctx.token, ctx.module, ctx.freq_only = plan, ws, token, module, freq_only
             ctx.save_for_backward(weight, bias, gamma, beta)
         ctx.need_grad = need_grad
+        ctx.eval_mode = not training
         return out
 
     @staticmethod
     def backward(ctx, dout):
+        if ctx.needs_input_grad[0]:
+            raise TbnHipError("BNInception: the gradient with respect to the input frames is not implemented (the "
+                              "first conv's data gradient is never formed); detach the input")
         if not ctx.need_grad:
+            if ctx.eval_mode and any(ctx.needs_input_grad[1:7]):
+                raise TbnHipError("BNInception: backward through an eval-mode backbone (running-statistics BN) is not "
+                                  "implemented; call .train() for fine-tuning or wrap inference in torch.no_grad()")
             return (None,) * 9
         weight, bias, gamma, beta = ctx.saved_tensors
         plan, ws, module = ctx.plan, ctx.ws, ctx.module

@@ -10,6 +10,15 @@ A backbone's all-reduce is issued as soon as autograd has accumulated its flat g
 backbones whose backward was enqueued later are still running on their own HIP streams; the packed
 small-tensor collective goes last.  No collective on the data path.
 
+The collective SCHEDULE is the same on every rank by construction: the packed buffer always holds every
+small trainable parameter in registration order (a missing gradient travels as zeros), and a large tensor is
+reduced from inside its gradient hook only if the wrapped module does not declare it optional.  Parameters the
+module lists in `maybe_unused_parameter_prefixes()` -- the audio backbone and the attention stack while
+`data.audio.dropout > 0`: reference model.py:215-222 draws the drop decision per replica, so one rank may produce
+those gradients while another does not -- are reduced at the end of backward in registration order, zero-filled
+where absent, together with one presence flag each; a parameter no rank produced a gradient for gets `grad = None`
+back, which is what the reference's optimiser sees when every nn.DataParallel replica dropped the audio feature.
+
 `DataParallel(model)` keeps the reference surface: `.module`, `forward`, `get_loss(...)`,
 `state_dict()` of the wrapped model under the `module.` prefix.
 """
@@ -19,14 +28,18 @@ import torch.nn as nn
 
 
 class DataParallel(nn.Module):
+    SMALL = 1 << 18   # elements: gradients below 1 MB travel together in one flat buffer (one collective)
+
     def __init__(self, module, device_ids=None, process_group=None, broadcast_parameters=True, overlap=True):
         super().__init__()
         self.module = module
         self.device_ids = device_ids
         self.process_group = process_group
         self.overlap = overlap          # False: every collective at the end of backward (diagnostic)
-        self._pending = []
-        self._ready = []
+        self.time_sync = False          # bench: bracket finish_gradient_sync with events (exposed all-reduce time)
+        self._sync_events = []
+        self._pending = []              # (param, work) of the collectives issued from gradient hooks
+        self._fired = set()             # ids of the parameters whose gradient hook ran in this backward
         self._callback_queued = False
         self._hooks = []
         self.world_size = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
@@ -38,14 +51,32 @@ class DataParallel(nn.Module):
                     self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad_ready))
 
     def broadcast_parameters(self, src=0):
-        """rank `src`'s parameters and buffers become everyone's (once, at wrap time)"""
+        """rank `src`'s parameters and buffers become everyone's (once, at wrap time): one broadcast per dtype over a
+        flat buffer -- the same coalescing the gradient all-reduce uses -- instead of one per tensor (1464 of them)"""
         with torch.no_grad():
-            for t in list(self.module.parameters()) + list(self.module.buffers()):
-                dist.broadcast(t, src, group=self.process_group)
+            tensors = list(self.module.parameters()) + list(self.module.buffers())
+            by_dtype = {}
+            for t in tensors:
+                by_dtype.setdefault((t.dtype, t.device), []).append(t)
+            for group in by_dtype.values():
+                flat = torch.cat([t.reshape(-1) for t in group])
+                dist.broadcast(flat, src, group=self.process_group)
+                off = 0
+                for t in group:
+                    t.copy_(flat[off:off + t.numel()].view_as(t))
+                    off += t.numel()
 
     def _reduce_op(self):
         avg = dist.get_backend(self.process_group) == "nccl"
         return avg, (dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM)
+
+    def _optional_ids(self):
+        """parameters that may legitimately get no gradient on some ranks in this step (declared by the module)"""
+        fn = getattr(self.module, "maybe_unused_parameter_prefixes", None)
+        prefixes = tuple(fn()) if fn is not None else ()
+        if not prefixes:
+            return set()
+        return {id(p) for n, p in self.module.named_parameters() if p.requires_grad and n.startswith(prefixes)}
 
     def _on_grad_ready(self, p):
         """post-accumulate-grad hook.  A large (flat backbone) gradient is all-reduced right here: the hook
@@ -53,49 +84,86 @@ class DataParallel(nn.Module):
         producing backbone's side stream (the stream semantics torch's own DDP reducer relies on), and the
         process group orders its collective after the current stream -- so the transfer starts when THAT
         backbone's backward has finished on the GPU, under the backward of the others.  Hooks fire in the
-        same (reverse-forward) order on every rank, so the collectives match up.  Small tensors are only
-        remembered; one callback at the end of backward packs and reduces them and waits for everything."""
-        if self.overlap and p.grad is not None and p.grad.numel() >= self.SMALL:
-            _, op = self._reduce_op()
-            self._pending.append((p.grad, dist.all_reduce(p.grad, op=op, group=self.process_group, async_op=True)))
-        else:
-            self._ready.append(p)
+        same (reverse-forward) order on every rank and only for parameters every rank produces (optional ones
+        wait for the end), so the collectives match up.  Small tensors are only remembered; one callback at
+        the end of backward packs and reduces them and waits for everything."""
         if not self._callback_queued:
             self._callback_queued = True
+            self._optional = self._optional_ids()
             torch.autograd.Variable._execution_engine.queue_callback(self.finish_gradient_sync)
-
-    SMALL = 1 << 18   # elements: gradients below 1 MB travel together in one flat buffer (one collective)
+        self._fired.add(id(p))
+        if self.overlap and p.grad is not None and p.grad.numel() >= self.SMALL and id(p) not in self._optional:
+            _, op = self._reduce_op()
+            self._pending.append((p, dist.all_reduce(p.grad, op=op, group=self.process_group, async_op=True)))
 
     def finish_gradient_sync(self):
         """average every gradient produced by this backward across ranks (RCCL all-reduce): one collective per
         large (flat backbone) tensor -- already in flight when `overlap` -- and ONE for all the small head /
-        bias / BN tensors together"""
+        bias / BN tensors together.  Runs as the autograd engine's final callback, before backward() returns."""
         avg, op = self._reduce_op()
-        grads = [p.grad for p in self._ready if p.grad is not None]
-        small = [g for g in grads if g.numel() < self.SMALL]
-        large = [g for g in grads if g.numel() >= self.SMALL]
+        ev0 = None
+        if self.time_sync and torch.cuda.is_available():
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+        optional = getattr(self, "_optional", set())
+        in_flight = {id(p) for p, _ in self._pending}
+        params = [p for p in self.module.parameters() if p.requires_grad]      # registration order: rank independent
+        present = {}
+        for p in params:
+            if id(p) in optional:
+                present[id(p)] = p.grad is not None and id(p) in self._fired
+                if not present[id(p)]:
+                    p.grad = torch.zeros_like(p)         # this rank dropped it: contributes zeros, same schedule
+        # a non-optional parameter without a gradient is skipped -- on every rank alike (same contract as torch DDP
+        # with find_unused_parameters=False); small ones still travel (as zeros) so that the packed size is fixed
+        late_large = [p for p in params if p.numel() >= self.SMALL and id(p) not in in_flight and p.grad is not None]
+        small = [p for p in params if p.numel() < self.SMALL]
         works = [w for _, w in self._pending]
-        works += [dist.all_reduce(g, op=op, group=self.process_group, async_op=True) for g in large]
-        large = [g for g, _ in self._pending] + large
+        works += [dist.all_reduce(p.grad, op=op, group=self.process_group, async_op=True) for p in late_large]
+        opt_list = [p for p in params if id(p) in optional]
         flat = None
-        if small:
-            flat = torch.cat([g.reshape(-1) for g in small])
+        if small or opt_list:
+            ref = (small or opt_list)[0]
+            pieces = [(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in small]
+            flags = torch.tensor([1.0 if present[id(p)] else 0.0 for p in opt_list], dtype=ref.dtype, device=ref.device)
+            flat = torch.cat(pieces + [flags])
             works.append(dist.all_reduce(flat, op=op, group=self.process_group, async_op=True))
         for work in works:
             work.wait()          # stream-level wait on RCCL; host-blocking only on gloo
         if not avg:
-            for g in large:
-                g.div_(self.world_size)
+            for p, _ in self._pending:
+                p.grad.div_(self.world_size)
+            for p in late_large:
+                p.grad.div_(self.world_size)
             if flat is not None:
                 flat.div_(self.world_size)
         if flat is not None:
             off = 0
-            for g in small:
-                g.copy_(flat[off:off + g.numel()].view_as(g))
-                off += g.numel()
-        self._ready = []
+            for p in small:
+                if p.grad is not None:
+                    p.grad.copy_(flat[off:off + p.numel()].view_as(p))
+                off += p.numel()
+            if opt_list:
+                # one host read per step, only while the module declares optional parameters (audio dropout)
+                anyone = flat[off:off + len(opt_list)].cpu() > 0
+                for p, a in zip(opt_list, anyone.tolist()):
+                    if not a:
+                        p.grad = None                      # no replica produced it: the optimiser skips it
+        if ev0 is not None:
+            ev1.record()
+            self._sync_events.append((ev0, ev1))
         self._pending = []
+        self._fired = set()
         self._callback_queued = False
+
+    def exposed_sync_ms(self):
+        """mean GPU time the compute stream spent inside finish_gradient_sync (the all-reduce tail that backward did
+        not hide + the small-tensor packing) over the steps recorded with `time_sync`; call after a device sync"""
+        if not self._sync_events:
+            return None
+        ms = [a.elapsed_time(b) for a, b in self._sync_events]
+        self._sync_events = []
+        return sum(ms) / len(ms)
 
     def forward(self, *args, **kwargs):
         return self.module(*args, **kwargs)

@@ -124,6 +124,15 @@ class TBNModel(nn.Module):
             # reference: every BatchNorm2d child with index > 1, i.e. all but conv1_7x7_s2_bn
             base.set_bn_trainable(first=True, rest=False)
 
+    def maybe_unused_parameter_prefixes(self):
+        """parameters that may get no gradient in a step: with `data.audio.dropout > 0` the per-replica host draw of
+        reference model.py:215-222 can drop the audio feature on one data-parallel rank and keep it on another --
+        `DataParallel` reduces these with a rank-independent schedule (zero-filled where absent)"""
+        if (self.training and len(self.modality) > 1 and "Audio" in self.modality
+                and self.cfg.data.audio.dropout > 0):
+            return ["Base_Audio.", "pe.", "attention_layer."]
+        return []
+
     def _aggregate_scores(self, scores, new_shape=(1, -1)):
         assert isinstance(scores, (dict, torch.Tensor))
         assert isinstance(new_shape, tuple)
@@ -200,6 +209,10 @@ class TBNModel(nn.Module):
         out = self.classifier(features, consensus=(b, n))
 
         if self.use_attention and not att.use_fixed and len(self.modality) > 1:
+            if att_wts is None:
+                # reference model.py:259-260 reads `att_wts` although the dropped-audio branch (:215-222) never binds it
+                raise UnboundLocalError("local variable 'att_wts' referenced before assignment (audio dropout with a "
+                                        "trainable attention layer: the reference fails the same way)")
             out["weights"] = att_wts
         return out
 

@@ -27,11 +27,16 @@ def build_model(cfg, modality, device, pretrained_state=None):
         "Model type '{}' not supported on the MI355X hot path (bninception only)".format(cfg.model.arch)
     assert cfg.model.loss_fn in _LOSS_TYPES.keys(), "Loss type '{}' not supported".format(cfg.model.loss_fn)
     world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
-    if len(cfg.gpu_ids) > 0:
-        num_gpus = len(cfg.gpu_ids)
-    else:
-        num_gpus = max(world, 1) if device.type == "cuda" else 0
-    assert world > 1 or num_gpus <= max(torch.cuda.device_count(), 1), "Cannot use more GPU devices than available"
+    requested = len(cfg.gpu_ids) if len(cfg.gpu_ids) > 0 else (max(world, 1) if device.type == "cuda" else 0)
+    if device.type == "cuda" and requested > 1 and world == 1:
+        # the reference would wrap in single-process nn.DataParallel here (model_builder.py:73-75); this path is one
+        # process per GPU -- fail now, not at the first checkpoint an epoch later
+        raise RuntimeError(f"gpu_ids lists {requested} GPUs but this process is not a rank of a torch.distributed job: "
+                           f"launch one process per GPU (python -m torch.distributed.run --nproc-per-node {requested} ...)")
+    assert world == 1 or len(cfg.gpu_ids) in (0, world), \
+        f"gpu_ids lists {len(cfg.gpu_ids)} GPUs but the torch.distributed world has {world} ranks"
+    # > 1 exactly when the model is wrapped (callers unwrap `.module` on it, reference misc.py:93-112)
+    num_gpus = world if (world > 1 and device.type == "cuda") else min(requested, 1)
 
     model = _MODEL_TYPES[cfg.model.arch](cfg, modality, device, pretrained_state=pretrained_state)
 

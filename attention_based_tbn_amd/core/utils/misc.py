@@ -20,7 +20,7 @@ def get_time_diff(start_time, end_time):
 
 def save_checkpoint(model, optimizer, epoch, train_loss_hist, val_loss_hist, val_acc_hist, confusion_matrix,
                     num_gpus, scheduler=None, filename="checkpoint.pth"):
-    target = model.module if num_gpus > 1 else model
+    target = getattr(model, "module", model) if num_gpus > 1 else model
     # the optimiser state is written over the reference's per-layer parameter list, so the file loads in the
     # reference (`optimizer.load_state_dict`) as well as here
     data = {"epoch": epoch, "train_loss": train_loss_hist, "validation_loss": val_loss_hist,

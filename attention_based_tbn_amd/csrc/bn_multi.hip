@@ -1,4 +1,4 @@
-// Batched ("multi-tensor") training-BN kernels: the BN steps of up to three INDEPENDENT conv layers in one launch.
+// Batched ("multi-tensor") training-BN kernels: the BN steps of up to four INDEPENDENT BN layers in one launch.
 //
 // Inside an inception block the 3x3, double_3x3_1 and pool_proj convs only depend on the fused 1x1 group, so
 // their BN finalize / apply (forward) and BN-backward reduce / finalize / apply form three identical little
@@ -37,8 +37,8 @@ __global__ __launch_bounds__(256) void bn_finalize_multi_kernel(BnFwdBatch b) {
   double a = 0.0, s = 0.0;
   if (c < C)
     for (int i = slot; i < L.nparts; i += 32) {
-      a += (double)L.partial[((size_t)i * 2 + 0) * C + c];
-      s += (double)L.partial[((size_t)i * 2 + 1) * C + c];
+      a += (double)L.partial[((size_t)i * 2 + 0) * L.pld + c];
+      s += (double)L.partial[((size_t)i * 2 + 1) * L.pld + c];
     }
   red[0][slot][cl] = a;
   red[1][slot][cl] = s;
@@ -75,9 +75,10 @@ __global__ __launch_bounds__(256) void bn_apply_multi_kernel(BnFwdBatch b) {
   const int C = L.C, G = C >> 2;
   const size_t total = (size_t)L.P * G;
   const float* y = L.y;
+  const int yld = L.y_ld;
   for (size_t i = (size_t)blk * 256 + threadIdx.x; i < total; i += (size_t)grid * 256) {
     const int p = (int)(i / G), c = (int)(i - (size_t)p * G) * 4;
-    const float4 v = *reinterpret_cast<const float4*>(y + (size_t)p * C + c);
+    const float4 v = *reinterpret_cast<const float4*>(y + (size_t)p * yld + c);
     const float4 sc = *reinterpret_cast<const float4*>(L.scale + c);
     const float4 sh = *reinterpret_cast<const float4*>(L.shift + c);
     float4 z;
@@ -97,7 +98,8 @@ int tbn_launch_bn_fwd_multi(BnFwdBatch& b, hipStream_t st) {
   b.fin_blk0[0] = b.app_blk0[0] = 0;
   for (int i = 0; i < b.n; ++i) {
     const BnFwdLayer& L = b.l[i];
-    TBN_REQUIRE(L.C % 4 == 0 && L.nseg >= 1 && L.nseg <= 3, "bn_fwd_multi: bad C / nseg");
+    TBN_REQUIRE(L.C % 4 == 0 && L.y_ld % 4 == 0 && L.y_ld >= L.C && L.pld >= L.C && L.nseg >= 1 && L.nseg <= 3,
+                "bn_fwd_multi: bad C / pitch / nseg");
     for (int s = 0; s < L.nseg; ++s)
       TBN_REQUIRE(L.seg[s].ld % 4 == 0 && L.seg[s].col_begin % 4 == 0, "bn_fwd_multi: segment pitch/offset must be x4");
     b.fin_blk0[i + 1] = b.fin_blk0[i] + cdiv(L.C, 8);
@@ -133,8 +135,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_multi_kernel(BnBwdBatch b) 
     const float4 mu = *reinterpret_cast<const float4*>(L.mean + c);
     const float4 rs4 = *reinterpret_cast<const float4*>(L.rstd + c);
     const float* y = L.y;
+    const int yld = L.y_ld;
     for (int p = p0 + rs; p < p1; p += RP) {
-      const float4 v = *reinterpret_cast<const float4*>(y + (size_t)p * C + c);
+      const float4 v = *reinterpret_cast<const float4*>(y + (size_t)p * yld + c);
       const float4 d = *reinterpret_cast<const float4*>(dzp + (size_t)p * dld);
       const float gx = fmaf(v.x, sc.x, sh.x) > 0.f ? d.x : 0.f;
       const float gy = fmaf(v.y, sc.y, sh.y) > 0.f ? d.y : 0.f;
@@ -205,13 +208,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_multi_kernel(BnBwdBatch b) {
   const size_t total = (size_t)L.P * G;
   const float* y = L.y;
   float* dy = L.dy;
+  const int yld = L.y_ld;
   for (size_t i = (size_t)blk * 256 + threadIdx.x; i < total; i += (size_t)grid * 256) {
     const int p = (int)(i / G), c = (int)(i - (size_t)p * G) * 4;
     int sg = 0;
     if (L.nseg > 1 && c >= L.dz[1].col_begin) sg = 1;
     if (L.nseg > 2 && c >= L.dz[2].col_begin) sg = 2;
     const float4 d = *reinterpret_cast<const float4*>(L.dz[sg].ptr + (size_t)p * L.dz[sg].ld + (c - L.dz[sg].col_begin));
-    const float4 v = *reinterpret_cast<const float4*>(y + (size_t)p * C + c);
+    const float4 v = *reinterpret_cast<const float4*>(y + (size_t)p * yld + c);
     const float4 sc = *reinterpret_cast<const float4*>(L.scale + c);
     const float4 sh = *reinterpret_cast<const float4*>(L.shift + c);
     const float4 ca = *reinterpret_cast<const float4*>(L.coef + c);
@@ -222,7 +226,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_multi_kernel(BnBwdBatch b) {
     o.y = fmaf(ca.y, fmaf(v.y, sc.y, sh.y) > 0.f ? d.y : 0.f, fmaf(cb.y, v.y, cc.y));
     o.z = fmaf(ca.z, fmaf(v.z, sc.z, sh.z) > 0.f ? d.z : 0.f, fmaf(cb.z, v.z, cc.z));
     o.w = fmaf(ca.w, fmaf(v.w, sc.w, sh.w) > 0.f ? d.w : 0.f, fmaf(cb.w, v.w, cc.w));
-    *reinterpret_cast<float4*>(dy + (size_t)p * C + c) = o;
+    *reinterpret_cast<float4*>(dy + (size_t)p * yld + c) = o;
   }
 }
 
@@ -231,7 +235,8 @@ int tbn_launch_bn_bwd_multi(BnBwdBatch& b, hipStream_t st) {
   b.red_blk0[0] = b.fin_blk0[0] = b.app_blk0[0] = 0;
   for (int i = 0; i < b.n; ++i) {
     BnBwdLayer& L = b.l[i];
-    TBN_REQUIRE(L.C % 4 == 0 && L.C <= 1024 && L.nseg >= 1 && L.nseg <= 3, "bn_bwd_multi: bad C / nseg");
+    TBN_REQUIRE(L.C % 4 == 0 && L.C <= 1024 && L.y_ld % 4 == 0 && L.y_ld >= L.C && L.nseg >= 1 && L.nseg <= 3,
+                "bn_bwd_multi: bad C / pitch / nseg");
     for (int s = 0; s < L.nseg; ++s)
       TBN_REQUIRE(L.dz[s].ld % 4 == 0 && L.dz[s].col_begin % 4 == 0, "bn_bwd_multi: segment pitch/offset must be x4");
     {  // same chunking as bn.hip's single-layer launch: rows per workgroup rounded to the row-lane count
@@ -241,12 +246,19 @@ int tbn_launch_bn_bwd_multi(BnBwdBatch& b, hipStream_t st) {
       L.pch = cdiv(pch, rp) * rp;
       L.nparts = cdiv(L.P, L.pch);
     }
-    b.red_blk0[i + 1] = b.red_blk0[i] + L.nparts;
+    int red_blocks = L.nparts;
+    if (L.ext_parts > 0) {   // partials came from the data-gradient epilogue that finished dz: nothing to reduce
+      L.nparts = L.ext_parts;
+      red_blocks = 0;
+    }
+    b.red_blk0[i + 1] = b.red_blk0[i] + red_blocks;
     b.fin_blk0[i + 1] = b.fin_blk0[i] + cdiv(L.C, 8);
     b.app_blk0[i + 1] = b.app_blk0[i] + ew_grid((size_t)L.P * L.C / 4);
   }
-  hipLaunchKernelGGL(bn_bwd_reduce_multi_kernel, dim3(b.red_blk0[b.n]), dim3(256), 0, st, b);
-  TBN_CHECK_LAUNCH("bn_bwd_reduce_multi");
+  if (b.red_blk0[b.n] > 0) {
+    hipLaunchKernelGGL(bn_bwd_reduce_multi_kernel, dim3(b.red_blk0[b.n]), dim3(256), 0, st, b);
+    TBN_CHECK_LAUNCH("bn_bwd_reduce_multi");
+  }
   hipLaunchKernelGGL(bn_bwd_finalize_multi_kernel, dim3(b.fin_blk0[b.n]), dim3(256), 0, st, b);
   TBN_CHECK_LAUNCH("bn_bwd_finalize_multi");
   hipLaunchKernelGGL(bn_bwd_apply_multi_kernel, dim3(b.app_blk0[b.n]), dim3(256), 0, st, b);

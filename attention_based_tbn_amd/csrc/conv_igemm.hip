@@ -75,7 +75,9 @@ __device__ __forceinline__ float4 buf_load4(i32x4 r, unsigned voff, unsigned sof
 
 // EPI: 0 plain (+bias, optional ReLU / accumulate), 1 training-BN statistics, 2 eval-BN fold + ReLU,
 //      3 plain with output scatter (parity phase of a strided data gradient)
-template <int MT, int NT, bool ROWMODE, int EPI, int STAGES>
+// RED (EPI 0 / 3 only): the epilogue also forms the BN-backward reduce partials of the layers that produced the
+//      activation whose gradient this launch finishes (RedSeg in tbn_kernels.h)
+template <int MT, int NT, bool ROWMODE, int EPI, int STAGES, bool RED = false>
 __device__ __forceinline__ void conv_igemm_body(const ConvP& p, const int bid, float* lds) {
   constexpr int BM = 128 * MT, BN = 32 * NT;
   constexpr int AR = 4 * MT;  // A rows per thread
@@ -289,6 +291,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& p, const int bid, f
   const int mrow0 = m0 + wave * 32 * MT + 4 * lhalf;  // + i*32 + 8*g + q  (accumulator register e = 4*g + q)
   const bool tile_full = (m0 + BM <= p.M);
   constexpr bool scatter = (EPI == 3);  // strided data-gradient phase
+  constexpr bool SUMS = (EPI == 1) || RED;   // (the K loop ends with a barrier: `red` may overlay the tiles)
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     const int colb = n0 + j * 32;
@@ -298,19 +301,51 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& p, const int bid, f
     int sg = 0;
     if (p.nseg > 1 && colb >= p.seg[1].col_begin) sg = 1;
     if (p.nseg > 2 && colb >= p.seg[2].col_begin) sg = 2;
+    if (p.nseg > 3 && colb >= p.seg[3].col_begin) sg = 3;
     const int old = p.seg[sg].ld;
     const i32x4 o_rsrc = make_rsrc(p.seg[sg].ptr, p.seg_bytes[sg]);
     const unsigned col_off = (unsigned)(col - p.seg[sg].col_begin) * 4u;
     const float bias = (EPI == 0 || EPI == 3) ? ((p.bias != nullptr && col_ok) ? p.bias[col] : 0.f) : 0.f;
     float sc = 1.f, sh = 0.f;
-    if (EPI == 2 && col_ok) {
-      sc = p.scale[col];
-      sh = p.shift[col];
+    bool raw = false;
+    if (EPI == 2) {
+      raw = (p.raw_seg1 == sg + 1);   // block-uniform
+      if (col_ok && !raw) {
+        sc = p.scale[col];
+        sh = p.shift[col];
+      }
+    }
+    // fused BN-backward reduce: the producer layer of these 32 columns (block-uniform, segments start on x32 columns)
+    int rs = 0;
+    bool red_on = false;
+    i32x4 y_rsrc = o_rsrc;
+    unsigned ycol_off = 0u;
+    int yld = 0;
+    float b_sc = 0.f, b_sh = 0.f, b_mu = 0.f, b_rs = 0.f;
+    if (RED) {
+      if (p.nred > 1 && colb >= p.red[1].col_begin) rs = 1;
+      if (p.nred > 2 && colb >= p.red[2].col_begin) rs = 2;
+      if (p.nred > 3 && colb >= p.red[3].col_begin) rs = 3;
+      red_on = p.red[rs].y != nullptr && colb < p.red[rs].col_begin + p.red[rs].C;
+      if (red_on) {
+        y_rsrc = make_rsrc(p.red[rs].y, p.red[rs].y_bytes);
+        yld = p.red[rs].y_ld;
+        const int lc = col - p.red[rs].col_begin;
+        ycol_off = (unsigned)lc * 4u;
+        if (lc < p.red[rs].C) {
+          const float* stp = p.red[rs].stats + p.red[rs].c_off + lc;
+          b_mu = stp[0];
+          b_rs = stp[p.red_chan];
+          b_sc = stp[2 * p.red_chan];
+          b_sh = stp[3 * p.red_chan];
+        }
+      }
     }
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
       const unsigned vbase = col_ok ? (unsigned)(mrow0 + i * 32) * (unsigned)old * 4u + col_off : TBN_OOB;
+      const unsigned ybase = (RED && red_on && col_ok) ? (unsigned)(mrow0 + i * 32) * (unsigned)yld * 4u + ycol_off : TBN_OOB;
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int dm = 8 * (e >> 2) + (e & 3);
@@ -319,11 +354,12 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& p, const int bid, f
           s1 += v;
           s2 = fmaf(v, v, s2);
         } else if (EPI == 2) {
-          v = fmaxf(fmaf(v, sc, sh), 0.f);
+          if (!raw) v = fmaxf(fmaf(v, sc, sh), 0.f);
         } else {
           v += bias;
         }
         unsigned voff = vbase, soff = (unsigned)(dm * old) * 4u;
+        unsigned yvoff = ybase, ysoff = (unsigned)(dm * yld) * 4u;
         if (scatter) {
           const int m = mrow0 + i * 32 + dm;
           const uint32_t n = fdiv((uint32_t)m, p.div_ohw);
@@ -333,18 +369,30 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& p, const int bid, f
           const unsigned opix = (unsigned)(((int)n * p.OH + ((int)a * p.out_sy + p.out_oy)) * p.OW + ((int)b * p.out_sx + p.out_ox));
           voff = (m < p.M && col_ok) ? opix * (unsigned)old * 4u + col_off : TBN_OOB;
           soff = 0u;
+          if (RED) {
+            yvoff = (m < p.M && col_ok && red_on) ? opix * (unsigned)yld * 4u + ycol_off : TBN_OOB;
+            ysoff = 0u;
+          }
         } else if (!tile_full) {
           const int m = mrow0 + i * 32 + dm;
           voff = (m < p.M) ? vbase : TBN_OOB;  // the scalar offset is not bounds-checked: mask the row here
+          if (RED) yvoff = (m < p.M) ? ybase : TBN_OOB;
         }
         if (EPI == 0 || EPI == 3) {
           if (p.flags & CONV_FLAG_ACCUM) v += tbn_llvm_buffer_load_f32(o_rsrc, (int)voff, (int)soff, 0);
           if (p.flags & CONV_FLAG_RELU) v = fmaxf(v, 0.f);
         }
         tbn_llvm_buffer_store_f32(v, o_rsrc, (int)voff, (int)soff, 0);
+        if (RED) {
+          // rows >= M / masked lanes: v may hold junk only where the store was masked too -> mask g the same way
+          const float yv = tbn_llvm_buffer_load_f32(y_rsrc, (int)yvoff, (int)ysoff, 0);
+          const float g = (yvoff != TBN_OOB && fmaf(yv, b_sc, b_sh) > 0.f) ? v : 0.f;
+          s1 += g;
+          s2 = fmaf(g, (yv - b_mu) * b_rs, s2);
+        }
       }
     }
-    if (EPI == 1) {
+    if (SUMS) {
       s1 += __shfl_xor(s1, 32);
       s2 += __shfl_xor(s2, 32);
       if (lhalf == 0) {
@@ -353,7 +401,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& p, const int bid, f
       }
     }
   }
-  if (EPI == 1) {
+  if (SUMS) {
     __syncthreads();
     if (tid < BN && n0 + tid < p.Cout) {
       float t1 = 0.f, t2 = 0.f;
@@ -362,16 +410,30 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& p, const int bid, f
         t1 += red[(0 * 4 + w) * BN + tid];
         t2 += red[(1 * 4 + w) * BN + tid];
       }
-      p.stat_partial[((size_t)tm * 2 + 0) * p.Cout + n0 + tid] = t1;
-      p.stat_partial[((size_t)tm * 2 + 1) * p.Cout + n0 + tid] = t2;
+      if (EPI == 1) {
+        p.stat_partial[((size_t)tm * 2 + 0) * p.Cout + n0 + tid] = t1;
+        p.stat_partial[((size_t)tm * 2 + 1) * p.Cout + n0 + tid] = t2;
+      } else {
+        const int col = n0 + tid;
+        int rs = 0;
+        if (p.nred > 1 && col >= p.red[1].col_begin) rs = 1;
+        if (p.nred > 2 && col >= p.red[2].col_begin) rs = 2;
+        if (p.nred > 3 && col >= p.red[3].col_begin) rs = 3;
+        const int lc = col - p.red[rs].col_begin;
+        if (p.red[rs].y != nullptr && lc < p.red[rs].C) {
+          float* part = p.red[rs].partial + (size_t)(p.red_row0 + tm) * 2 * p.red[rs].C;
+          part[lc] = t1;
+          part[p.red[rs].C + lc] = t2;
+        }
+      }
     }
   }
 }
 
-template <int MT, int NT, bool ROWMODE, int EPI, int STAGES>
+template <int MT, int NT, bool ROWMODE, int EPI, int STAGES, bool RED = false>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
   __shared__ __attribute__((aligned(16))) float lds[STAGES * (128 * MT + 32 * NT) * LDT];
-  conv_igemm_body<MT, NT, ROWMODE, EPI, STAGES>(p, blockIdx.x, lds);
+  conv_igemm_body<MT, NT, ROWMODE, EPI, STAGES, RED>(p, blockIdx.x, lds);
 }
 
 // The four output-parity phases of a stride-2 data gradient in ONE launch: each phase alone is a small GEMM
@@ -381,12 +443,12 @@ struct ConvPhases {
   int blk0[5];
   int n;
 };
-template <int MT, int NT, int STAGES>
+template <int MT, int NT, int STAGES, bool RED = false>
 __global__ __launch_bounds__(256) void conv_igemm_phases_kernel(ConvPhases q) {
   __shared__ __attribute__((aligned(16))) float lds[STAGES * (128 * MT + 32 * NT) * LDT];
   int ph = 0;
   while (ph + 1 < q.n && (int)blockIdx.x >= q.blk0[ph + 1]) ++ph;
-  conv_igemm_body<MT, NT, false, 3, STAGES>(q.ph[ph], blockIdx.x - q.blk0[ph], lds);
+  conv_igemm_body<MT, NT, false, 3, STAGES, RED>(q.ph[ph], blockIdx.x - q.blk0[ph], lds);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -634,12 +696,12 @@ __global__ void weight_flip_transpose_kernel(const float* __restrict__ w, float*
 }
 
 // ------------------------------------------------------------------------------------------ host
-template <int MT, int NT, bool RM, int EPI>
+template <int MT, int NT, bool RM, int EPI, bool RED = false>
 static void launch_conv_e(const ConvP& p, hipStream_t st) {
   if (p.stages == 2)
-    hipLaunchKernelGGL((conv_igemm_kernel<MT, NT, RM, EPI, 2>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, st, p);
+    hipLaunchKernelGGL((conv_igemm_kernel<MT, NT, RM, EPI, 2, RED>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, st, p);
   else
-    hipLaunchKernelGGL((conv_igemm_kernel<MT, NT, RM, EPI, 1>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, st, p);
+    hipLaunchKernelGGL((conv_igemm_kernel<MT, NT, RM, EPI, 1, RED>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, st, p);
 }
 template <int MT, int NT, bool RM>
 static void launch_conv(const ConvP& p, hipStream_t st) {
@@ -650,6 +712,8 @@ static void launch_conv(const ConvP& p, hipStream_t st) {
     launch_conv_e<MT, NT, RM, 2>(p, st);
   else if (!RM && scatter)
     launch_conv_e<MT, NT, false, 3>(p, st);
+  else if (!RM && p.nred > 0)
+    launch_conv_e<MT, NT, false, 0, true>(p, st);
   else
     launch_conv_e<MT, NT, RM, 0>(p, st);
 }
@@ -678,6 +742,18 @@ void tbn_conv_pick_tile(int M, int Cout, int K, int* mt_out, int* nt_out) {
   *nt_out = bn;
 }
 
+// number of partial rows (M tiles) a data-gradient launch with a fused BN-backward reduce writes per reduce segment
+int tbn_conv_red_rows(int N, int OH, int OW, int up, int mt) {
+  if (up == 1) return cdiv(N * OH * OW, 128 * mt);
+  int rows = 0;
+  for (int py = 0; py < 2; ++py)
+    for (int px = 0; px < 2; ++px) {
+      const int ohs = (OH - py + 1) / 2, ows = (OW - px + 1) / 2;
+      if (ohs > 0 && ows > 0) rows += cdiv(N * ohs * ows, 128 * mt);
+    }
+  return rows;
+}
+
 static int launch_conv_tiles(ConvP& p, int rowmode, int mt, int nt, hipStream_t st) {
   if (mt <= 0 || nt <= 0) tbn_conv_pick_tile(p.M, p.Cout, p.K, &mt, &nt);
   if (p.stages != 1 && p.stages != 2) p.stages = (mt == 1) ? 2 : 1;  // big tiles: keep 2 workgroups per CU
@@ -686,7 +762,8 @@ static int launch_conv_tiles(ConvP& p, int rowmode, int mt, int nt, hipStream_t 
   {
     char nm[64];
     const int epi = p.mode == CONV_EPI_STATS ? 1 : (p.mode == CONV_EPI_EVAL ? 2 : ((p.out_sy != 1 || p.out_sx != 1) ? 3 : 0));
-    snprintf(nm, sizeof(nm), "conv_igemm_kernel<%d, %d, %s, %d, %d>", mt, nt, rowmode ? "true" : "false", epi, p.stages);
+    snprintf(nm, sizeof(nm), "conv_igemm_kernel<%d, %d, %s, %d, %d%s>", mt, nt, rowmode ? "true" : "false", epi, p.stages,
+             (p.nred > 0 && epi == 0 && !rowmode) ? ", true" : "");
     tbn_prof_begin(nm, p.alg_flops, st);
   }
 #define TBN_CASE(MTv, NTv)                                     \
@@ -714,7 +791,20 @@ static int launch_conv_tiles(ConvP& p, int rowmode, int mt, int nt, hipStream_t 
 int tbn_launch_conv(ConvP p, int rowmode, int mt, int nt, hipStream_t st) {
   TBN_REQUIRE(p.K % 32 == 0 && p.Cin % 32 == 0, "conv: K (%d) and per-tap Cin (%d) must be multiples of 32", p.K,
               p.Cin);
-  TBN_REQUIRE(p.in_ld % 4 == 0 && p.nseg >= 1 && p.nseg <= 3, "conv: bad in_ld %d / nseg %d", p.in_ld, p.nseg);
+  TBN_REQUIRE(p.in_ld % 4 == 0 && p.nseg >= 1 && p.nseg <= TBN_CONV_MAXSEG, "conv: bad in_ld %d / nseg %d", p.in_ld,
+              p.nseg);
+  TBN_REQUIRE(p.nred >= 0 && p.nred <= TBN_CONV_MAXSEG && (p.nred == 0 || (p.mode == CONV_EPI_PLAIN && !rowmode)),
+              "conv: the fused BN-backward reduce belongs to a plain (data-gradient) epilogue");
+  for (int i = 0; i < p.nred; ++i) {
+    TBN_REQUIRE(p.red[i].col_begin % 32 == 0 && (i == 0 ? p.red[i].col_begin == 0 : p.red[i].col_begin >= p.red[i - 1].col_begin + p.red[i - 1].C),
+                "conv: reduce segment %d starts at column %d (x32, ascending, disjoint)", i, p.red[i].col_begin);
+    if (p.red[i].y != nullptr) {
+      TBN_REQUIRE(p.red[i].partial && p.red[i].stats && p.red[i].C > 0, "conv: reduce segment %d incomplete", i);
+      const size_t yb = (((size_t)p.N * p.OH * p.OW - 1) * p.red[i].y_ld + p.red[i].C) * sizeof(float);
+      TBN_REQUIRE(yb < (1ull << 31), "conv: reduce segment extent %zu B >= 2 GiB", yb);
+      p.red[i].y_bytes = (unsigned)yb;
+    }
+  }
   TBN_REQUIRE(p.up == 1 || p.up == 2, "conv: up must be 1 or 2");
   TBN_REQUIRE(p.M > 0, "conv: empty problem");
   const size_t in_bytes = (size_t)p.N * p.H * p.W * (rowmode ? p.cp : p.in_ld) * sizeof(float);
@@ -825,26 +915,36 @@ int tbn_launch_conv(ConvP p, int rowmode, int mt, int nt, hipStream_t st) {
   if (pmt <= 0 || pnt <= 0) tbn_conv_pick_tile(phases.ph[0].M, p.Cout, phases.ph[0].K, &pmt, &pnt);
   const int stages = (p.stages == 1 || p.stages == 2) ? p.stages : ((pmt == 1) ? 2 : 1);
   phases.blk0[0] = 0;
+  int red_rows = p.red_row0;
   for (int i = 0; i < phases.n; ++i) {
     ConvP& q = phases.ph[i];
     q.stages = stages;
     q.tiles_m = cdiv(q.M, 128 * pmt);
     q.tiles_n = cdiv(q.Cout, 32 * pnt);
+    q.red_row0 = red_rows;      // the phases of one layer append their M tiles to the same partial buffers
+    red_rows += q.tiles_m;
     phases.blk0[i + 1] = phases.blk0[i] + q.tiles_m * q.tiles_n;
   }
   {
     char nm[64];
-    snprintf(nm, sizeof(nm), "conv_igemm_phases_kernel<%d, %d, %d>", pmt, pnt, stages);
+    snprintf(nm, sizeof(nm), "conv_igemm_phases_kernel<%d, %d, %d%s>", pmt, pnt, stages, p.nred > 0 ? ", true" : "");
     tbn_prof_begin(nm, flops_total, st);
   }
-#define TBN_PCASE(MTv, NTv)                                                                                        \
-  if (pmt == MTv && pnt == NTv) {                                                                                  \
-    if (stages == 2)                                                                                               \
-      hipLaunchKernelGGL((conv_igemm_phases_kernel<MTv, NTv, 2>), dim3(phases.blk0[phases.n]), dim3(256), 0, st,  \
-                         phases);                                                                                  \
-    else                                                                                                           \
-      hipLaunchKernelGGL((conv_igemm_phases_kernel<MTv, NTv, 1>), dim3(phases.blk0[phases.n]), dim3(256), 0, st,  \
-                         phases);                                                                                  \
+#define TBN_PLAUNCH(MTv, NTv, STv, REDv) \
+  hipLaunchKernelGGL((conv_igemm_phases_kernel<MTv, NTv, STv, REDv>), dim3(phases.blk0[phases.n]), dim3(256), 0, st, phases)
+#define TBN_PCASE(MTv, NTv)                          \
+  if (pmt == MTv && pnt == NTv) {                    \
+    if (stages == 2) {                               \
+      if (p.nred > 0)                                \
+        TBN_PLAUNCH(MTv, NTv, 2, true);              \
+      else                                           \
+        TBN_PLAUNCH(MTv, NTv, 2, false);             \
+    } else {                                         \
+      if (p.nred > 0)                                \
+        TBN_PLAUNCH(MTv, NTv, 1, true);              \
+      else                                           \
+        TBN_PLAUNCH(MTv, NTv, 1, false);             \
+    }                                                \
   } else
   TBN_PCASE(1, 1) TBN_PCASE(1, 2) TBN_PCASE(1, 3) TBN_PCASE(1, 4) TBN_PCASE(2, 1) TBN_PCASE(2, 2) TBN_PCASE(2, 3)
   TBN_PCASE(2, 4) {
@@ -852,6 +952,7 @@ int tbn_launch_conv(ConvP p, int rowmode, int mt, int nt, hipStream_t st) {
     return TBN_ERR_UNSUPPORTED;
   }
 #undef TBN_PCASE
+#undef TBN_PLAUNCH
   tbn_prof_end(st);
   TBN_CHECK_LAUNCH("conv_igemm_phases");
   return TBN_OK;

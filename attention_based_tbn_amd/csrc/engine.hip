@@ -6,9 +6,14 @@
 // MI355X-first choices (vs. the reference's one nn.Module call per layer):
 //   * NHWC activations; every branch writes straight into its channel slice of the block's
 //     concat buffer (no torch.cat copies);
-//   * the 1x1 convs that read the same block input (1x1, 3x3_reduce, double_3x3_reduce) run as ONE
-//     GEMM (their parameters are adjacent in the flat parameter arrays), forward and backward;
-//   * training-mode BatchNorm statistics are produced by the conv epilogue (no extra pass over y);
+//   * the 1x1 convs that read the same block input -- 1x1, 3x3_reduce, double_3x3_reduce AND pool_proj (a 3x3
+//     average pool and a bias-free 1x1 conv commute exactly, so the pool runs on pool_proj's few OUTPUT channels) --
+//     run as ONE GEMM forward, one weight-gradient GEMM and one data-gradient GEMM (their parameters are adjacent
+//     in the flat parameter arrays): the block input's gradient is written once instead of accumulated;
+//   * training-mode BatchNorm statistics are produced by the conv epilogue (no extra pass over y), and the
+//     BN-BACKWARD reduction (sum g, sum g*xhat) by the epilogue of the data-gradient GEMM that finishes dz
+//     (no extra pass over dz and y either);
+//   * the BN steps of the independent layers of a block run as batched (multi-tensor) launches;
 //   * all parameters of a backbone live in 6 flat arrays, gradients likewise -> the data-parallel
 //     all-reduce and the optimizer touch a handful of large tensors (RCCL/xGMI friendly);
 //   * the caller owns all memory: one workspace blob sized by tbn_backbone_workspace_bytes().
@@ -38,21 +43,35 @@ const BlockSpec kBlocks[] = {
     {"5a", 1056, 352, 192, 320, 160, 224, 224, 0, 128, 1}, {"5b", 1024, 352, 192, 320, 192, 224, 224, 1, 128, 1},
 };
 const int kNumBlocks = 10;
+const int kMaxParts = TBN_CONV_MAXSEG;
 
 struct Buf {
   int H, W, C;
   size_t off, doff;  // float offsets of z and dz in the workspace
 };
 
-struct Conv {
+// one reference conv + BatchNorm + ReLU: a column range ("part") of a GEMM
+struct Part {
+  std::string name;
+  int cout, col0;
+  int dst_buf, dst_choff;   // where z = relu(bn(.)) goes (a channel slice of a concat buffer)
+  size_t c_off;             // offset in the flat per-channel arrays
+  bool pooled = false;      // BN input = avg_pool3x3(conv output columns): pool_proj riding in the fused 1x1 GEMM
+  size_t y2_off = 0;        // pooled: the pooled conv output = BN input (P x cout, pitch cout)
+  size_t yraw_off = 0;      // pooled, eval mode: raw conv output (P x cout, pitch cout)
+  size_t bpart_off = 0;     // BN-backward partials written by the data-gradient epilogue of conv `red_src`
+  int red_src = -1;         // -1: own reduce kernel
+  int slot = 0;             // pooled: scratch slot of its forward statistics partials
+};
+
+struct Conv {   // one GEMM: up to four parts that read the same input (adjacent in the flat parameter arrays)
   int nparts;
-  std::string names[3];
-  int couts[3];
+  Part parts[kMaxParts];
   int cin, cout, k, stride, pad;
   int inbuf, inH, inW, outH, outW;
-  int dst_buf[3], dst_choff[3];
   size_t w_off, c_off;
-  size_t y_off;
+  size_t y_off;                 // training: raw conv output (P x cout); becomes dy in place during backward
+  int slot = 0;                 // forward statistics scratch slot
   int mt, nt, stages = 0;       // forward tile / LDS stages (0 = default)
   int d_mt, d_nt, d_stages = 0; // dgrad tile
   int w_mt = 0, w_nt = 0;       // wgrad tile (0 = heuristic)
@@ -60,9 +79,10 @@ struct Conv {
   bool dgrad_accum;    // dgrad adds into d(inbuf)
   bool need_dgrad;
   int fuse_pool = -1;  // training: index of the max pool that is the ONLY consumer of this conv's BN-ReLU output
-  int group = -1, group_pos = 0, group_size = 1;  // training: BN kernels batched with the other members (bn_multi.hip)
-  bool post_pool = false;  // 3x3 average pool between this 1x1 conv and its BN (see build_graph, pool_proj)
-  size_t y2_off = 0;       // post_pool: pooled conv output = BN input (y_off holds the un-pooled conv output)
+  // BN layers whose dz this conv's data gradient finishes (it is the last writer of d(inbuf)): their BN-backward
+  // reduce runs in its epilogue.  Ascending column order of inbuf.
+  int nred = 0;
+  int red_conv[kMaxParts], red_part[kMaxParts];
 };
 
 struct Pool {
@@ -73,9 +93,16 @@ struct Pool {
   bool fused = false;  // training: executed inside its producer conv's BN apply / BN backward (see Conv::fuse_pool)
 };
 
+struct BnStep {   // BN (+ReLU) of up to four independent layers: one finalize + one apply launch (three in backward)
+  int n;
+  int conv[kMaxParts], part[kMaxParts];
+};
+
+enum { OP_CONV = 0, OP_POOL = 1, OP_BN = 2, OP_PREPOOL = 3 };
 struct Op {
-  int kind;  // 0 conv, 1 pool
-  int idx;
+  int kind;
+  int idx;   // conv / pool / bn-step index; OP_PREPOOL: conv index
+  int part;  // OP_PREPOOL: part index
 };
 
 int pool_out(int in, int k, int stride, int pad, bool ceil_mode) {
@@ -97,6 +124,7 @@ struct tbn_backbone_plan {
   std::vector<Buf> bufs;
   std::vector<Conv> convs;
   std::vector<Pool> pools;
+  std::vector<BnStep> bns;
   std::vector<Op> ops;
   int out_buf;
   size_t weight_floats, chan_floats;
@@ -128,11 +156,15 @@ int add_conv(tbn_backbone_plan* P, int nparts, const std::string* names, const i
   Conv c;
   c.nparts = nparts;
   c.cout = 0;
+  c.c_off = P->chan_floats;
   for (int i = 0; i < nparts; ++i) {
-    c.names[i] = names[i];
-    c.couts[i] = couts[i];
-    c.dst_buf[i] = dst_buf[i];
-    c.dst_choff[i] = dst_choff[i];
+    Part& q = c.parts[i];
+    q.name = names[i];
+    q.cout = couts[i];
+    q.col0 = c.cout;
+    q.dst_buf = dst_buf[i];
+    q.dst_choff = dst_choff[i];
+    q.c_off = c.c_off + c.cout;
     c.cout += couts[i];
   }
   c.cin = cin;
@@ -146,14 +178,13 @@ int add_conv(tbn_backbone_plan* P, int nparts, const std::string* names, const i
   c.outW = (c.inW + 2 * pad - k) / stride + 1;
   c.stem = stem;
   c.w_off = P->weight_floats;
-  c.c_off = P->chan_floats;
   P->weight_floats += (size_t)c.cout * k * k * cin;
   P->chan_floats += c.cout;
   c.need_dgrad = !stem;
   c.dgrad_accum = false;
   c.y_off = 0;
   P->convs.push_back(c);
-  Op o = {0, (int)P->convs.size() - 1};
+  Op o = {OP_CONV, (int)P->convs.size() - 1, 0};
   P->ops.push_back(o);
   return o.idx;
 }
@@ -169,9 +200,32 @@ int add_pool(tbn_backbone_plan* P, int kind, int inbuf, int outbuf, int out_chof
   p.argmax_off = 0;
   p.bwd_accum = false;
   P->pools.push_back(p);
-  Op o = {1, (int)P->pools.size() - 1};
+  Op o = {OP_POOL, (int)P->pools.size() - 1, 0};
   P->ops.push_back(o);
   return o.idx;
+}
+
+void add_bn(tbn_backbone_plan* P, int n, const int* conv, const int* part) {
+  BnStep s;
+  s.n = n;
+  for (int i = 0; i < n; ++i) {
+    s.conv[i] = conv[i];
+    s.part[i] = part[i];
+  }
+  P->bns.push_back(s);
+  Op o = {OP_BN, (int)P->bns.size() - 1, 0};
+  P->ops.push_back(o);
+}
+
+// BN step over every (non-pooled) part of one conv
+void add_bn_conv(tbn_backbone_plan* P, int ci) {
+  int cs[kMaxParts], ps[kMaxParts], n = 0;
+  for (int i = 0; i < P->convs[ci].nparts; ++i)
+    if (!P->convs[ci].parts[i].pooled) {
+      cs[n] = ci;
+      ps[n++] = i;
+    }
+  add_bn(P, n, cs, ps);
 }
 
 // false: the input size makes the reference graph itself inconsistent (its torch.cat of a stride-2 conv branch and the
@@ -195,7 +249,7 @@ bool build_graph(tbn_backbone_plan* P) {
   {
     std::string n = "conv1_7x7_s2";
     int co = 64, db = c1, dc = 0;
-    add_conv(P, 1, &n, &co, cin0, 7, 2, 3, x0, &db, &dc, true);
+    add_bn_conv(P, add_conv(P, 1, &n, &co, cin0, 7, 2, 3, x0, &db, &dc, true));
   }
   int hp = pool_out(h1, 3, 2, 0, true), wp = pool_out(w1, 3, 2, 0, true);
   const int p1 = add_buf(P, hp, wp, 64);
@@ -204,13 +258,13 @@ bool build_graph(tbn_backbone_plan* P) {
   {
     std::string n = "conv2_3x3_reduce";
     int co = 64, db = c2r, dc = 0;
-    add_conv(P, 1, &n, &co, 64, 1, 1, 0, p1, &db, &dc, false);
+    add_bn_conv(P, add_conv(P, 1, &n, &co, 64, 1, 1, 0, p1, &db, &dc, false));
   }
   const int c2 = add_buf(P, hp, wp, 192);
   {
     std::string n = "conv2_3x3";
     int co = 192, db = c2, dc = 0;
-    add_conv(P, 1, &n, &co, 64, 3, 1, 1, c2r, &db, &dc, false);
+    add_bn_conv(P, add_conv(P, 1, &n, &co, 64, 3, 1, 1, c2r, &db, &dc, false));
   }
   int h = pool_out(hp, 3, 2, 0, true), w = pool_out(wp, 3, 2, 0, true);
   int x = add_buf(P, h, w, 192);
@@ -229,11 +283,15 @@ bool build_graph(tbn_backbone_plan* P) {
     const int T1 = add_buf(P, h, w, B.c3r);
     const int T2 = add_buf(P, h, w, B.cdr);
     const int T3 = add_buf(P, h, w, B.cd1);
-    int pool_in = x;
-    // fused 1x1 group on the block input
+    // fused 1x1 group on the block input: 1x1 | 3x3_reduce | double_3x3_reduce | pool_proj.
+    // reference: pool_proj(avg_pool3x3(x)).  A 3x3 / stride 1 / count_include_pad average and a (bias-free) 1x1
+    // conv commute exactly, so the conv runs on the block input -- as a fourth column range of this GEMM -- and the
+    // POOLING runs on its 32..128 output channels instead of the 192..1056 input channels.  The bias is added after
+    // the pool (it is folded into the BN statistics / shift like everywhere else), where the reference adds it.
+    int g, g_pp = -1;
     {
-      std::string names[3];
-      int couts[3], db[3], dc[3], n = 0;
+      std::string names[kMaxParts];
+      int couts[kMaxParts], db[kMaxParts], dc[kMaxParts], n = 0;
       if (B.c1) {
         names[n] = pre + "_1x1";
         couts[n] = B.c1;
@@ -251,11 +309,25 @@ bool build_graph(tbn_backbone_plan* P) {
       db[n] = T2;
       dc[n] = 0;
       ++n;
-      add_conv(P, n, names, couts, B.cin, 1, 1, 0, x, db, dc, false);
+      if (B.pool == 0) {
+        names[n] = pre + "_pool_proj";
+        couts[n] = B.cp;
+        db[n] = O;
+        dc[n] = B.c1 + B.c3 + B.cd2;
+        g_pp = n++;
+      }
+      g = add_conv(P, n, names, couts, B.cin, 1, 1, 0, x, db, dc, false);
+      if (g_pp >= 0) P->convs[g].parts[g_pp].pooled = true;
+      add_bn_conv(P, g);
+      if (g_pp >= 0) {
+        Op o = {OP_PREPOOL, g, g_pp};
+        P->ops.push_back(o);
+      }
     }
-    // The 3x3, double_3x3_1 and pool_proj convs only depend on the fused 1x1 group: they are issued back to back
-    // and share ONE batched BN finalize / apply (forward) and BN-backward reduce / finalize / apply launch set.
-    int members[3], nm = 0;
+    // The 3x3, double_3x3_1 and pool_proj layers only depend on the fused 1x1 group: their convs are issued back to
+    // back and they share ONE batched BN finalize / apply (forward) and BN-backward launch set.
+    int mc[kMaxParts], mp[kMaxParts], nm = 0;
+    int pool_in = x;
     if (B.pool == 1) {   // 5b: 3x3 / stride-1 max pool of the block input feeds pool_proj (not linear: stays in front)
       const int XP = add_buf(P, h, w, B.cin);
       add_pool(P, 1, x, XP, 0, 1, 1);
@@ -264,42 +336,36 @@ bool build_graph(tbn_backbone_plan* P) {
     {
       std::string n = pre + "_3x3";
       int co = B.c3, db = O, dc = B.c1;
-      members[nm++] = add_conv(P, 1, &n, &co, B.c3r, 3, B.stride, 1, T1, &db, &dc, false);
+      mc[nm] = add_conv(P, 1, &n, &co, B.c3r, 3, B.stride, 1, T1, &db, &dc, false);
+      P->convs[mc[nm]].slot = nm;
+      mp[nm++] = 0;
     }
     {
       std::string n = pre + "_double_3x3_1";
       int co = B.cd1, db = T3, dc = 0;
-      members[nm++] = add_conv(P, 1, &n, &co, B.cdr, 3, 1, 1, T2, &db, &dc, false);
+      mc[nm] = add_conv(P, 1, &n, &co, B.cdr, 3, 1, 1, T2, &db, &dc, false);
+      P->convs[mc[nm]].slot = nm;
+      mp[nm++] = 0;
     }
     if (B.pool == 2) {
       if (pool_out(h, 3, 2, 0, true) != oh || pool_out(w, 3, 2, 0, true) != ow) return false;
       add_pool(P, 1, x, O, B.c1 + B.c3 + B.cd2, 2, 0);
     } else if (B.pool == 0) {
-      // reference: pool_proj(avg_pool3x3(x)).  A 3x3 / stride 1 / count_include_pad average and a (bias-free) 1x1
-      // conv commute exactly, so the conv runs on the block input and the POOLING runs on its 32..128 output
-      // channels instead of the 192..1056 input channels: 5-8x fewer bytes through the HBM-bound pool kernels
-      // (forward and backward), no pooled copy of the block input.  The bias is added after the pool (it is folded
-      // into the BN statistics / shift like everywhere else), which is where the reference adds it.
-      std::string n = pre + "_pool_proj";
-      int co = B.cp, db = O, dc = B.c1 + B.c3 + B.cd2;
-      const int ci = add_conv(P, 1, &n, &co, B.cin, 1, 1, 0, x, &db, &dc, false);
-      P->convs[ci].post_pool = true;
-      members[nm++] = ci;
+      P->convs[g].parts[g_pp].slot = nm;
+      mc[nm] = g;
+      mp[nm++] = g_pp;
     } else {
       std::string n = pre + "_pool_proj";
       int co = B.cp, db = O, dc = B.c1 + B.c3 + B.cd2;
-      members[nm++] = add_conv(P, 1, &n, &co, B.cin, 1, 1, 0, pool_in, &db, &dc, false);
+      mc[nm] = add_conv(P, 1, &n, &co, B.cin, 1, 1, 0, pool_in, &db, &dc, false);
+      P->convs[mc[nm]].slot = nm;
+      mp[nm++] = 0;
     }
-    for (int k = 0; k < nm; ++k) {
-      Conv& c = P->convs[members[k]];
-      c.group = bi;
-      c.group_pos = k;
-      c.group_size = nm;
-    }
+    add_bn(P, nm, mc, mp);
     {
       std::string n = pre + "_double_3x3_2";
       int co = B.cd2, db = O, dc = B.c1 + B.c3;
-      add_conv(P, 1, &n, &co, B.cd1, 3, B.stride, 1, T3, &db, &dc, false);
+      add_bn_conv(P, add_conv(P, 1, &n, &co, B.cd1, 3, B.stride, 1, T3, &db, &dc, false));
     }
     x = O;
     h = oh;
@@ -307,20 +373,24 @@ bool build_graph(tbn_backbone_plan* P) {
   }
   P->out_buf = x;
 
-  // backward write order: walk ops in reverse, first writer of a d-buffer overwrites, later ones add
+  // backward write order: walk ops in reverse, first writer of a d-buffer overwrites, later ones add.  The LAST
+  // writer holds the final gradient in its epilogue.
   std::vector<char> written(P->bufs.size(), 0);
+  std::vector<int> last_conv(P->bufs.size(), -1);   // conv whose dgrad writes d(buf) last; -1: none / a pool
   for (int i = (int)P->ops.size() - 1; i >= 0; --i) {
     const Op& o = P->ops[i];
-    if (o.kind == 0) {
+    if (o.kind == OP_CONV) {
       Conv& c = P->convs[o.idx];
       if (c.need_dgrad) {
         c.dgrad_accum = written[c.inbuf] != 0;
         written[c.inbuf] = 1;
+        last_conv[c.inbuf] = o.idx;
       }
-    } else {
+    } else if (o.kind == OP_POOL) {
       Pool& p = P->pools[o.idx];
       p.bwd_accum = written[p.inbuf] != 0;
       written[p.inbuf] = 1;
+      last_conv[p.inbuf] = -1;
     }
   }
 
@@ -334,16 +404,48 @@ bool build_graph(tbn_backbone_plan* P) {
     Pool& q = P->pools[pi];
     if (q.kind != 1 || q.bwd_accum || readers[q.inbuf] != 1 || q.inbuf == P->out_buf) continue;
     for (auto& c : P->convs)
-      if (c.nparts == 1 && c.dst_buf[0] == q.inbuf && c.dst_choff[0] == 0 && c.cout == P->bufs[q.inbuf].C) {
+      if (c.nparts == 1 && c.parts[0].dst_buf == q.inbuf && c.parts[0].dst_choff == 0 && c.cout == P->bufs[q.inbuf].C) {
         c.fuse_pool = (int)pi;
         q.fused = true;
       }
+  }
+
+  // BN-backward reduce in the epilogue of the data gradient that finishes dz: every BN layer whose output buffer gets
+  // its final gradient from a conv's dgrad (not from outside, not through a fused pool).  Stride-2 dgrads (parity
+  // phases) take part as well.  The reduce segments of a conv must start on 32-column boundaries (epilogue sub-tiles).
+  for (size_t ci = 0; ci < P->convs.size(); ++ci) {
+    Conv& f = P->convs[ci];
+    if (!f.need_dgrad || last_conv[f.inbuf] != (int)ci || f.inbuf == P->out_buf) continue;
+    struct Cand { int conv, part, choff; };
+    std::vector<Cand> cand;
+    bool ok = true;
+    for (size_t cj = 0; cj < P->convs.size(); ++cj) {
+      const Conv& c = P->convs[cj];
+      for (int k = 0; k < c.nparts; ++k)
+        if (c.parts[k].dst_buf == f.inbuf) {
+          if (c.fuse_pool >= 0) ok = false;
+          cand.push_back({(int)cj, k, c.parts[k].dst_choff});
+        }
+    }
+    if (!ok || cand.empty() || (int)cand.size() > kMaxParts) continue;
+    for (size_t a = 0; a < cand.size(); ++a)
+      for (size_t b = a + 1; b < cand.size(); ++b)
+        if (cand[b].choff < cand[a].choff) std::swap(cand[a], cand[b]);
+    for (auto& cd : cand)
+      if (cd.choff % 32 != 0) ok = false;
+    if (!ok) continue;
+    f.nred = (int)cand.size();
+    for (int k = 0; k < f.nred; ++k) {
+      f.red_conv[k] = cand[k].conv;
+      f.red_part[k] = cand[k].part;
+      P->convs[cand[k].conv].parts[cand[k].part].red_src = (int)ci;
+    }
   }
   return true;
 }
 
 // Timing diagnostics only (-DTBN_DIAG=1 build, never shipped): TBN_DIAG_SKIP=<bit mask> drops kernel groups
-// (1 finalize, 2 bn_apply, 4 pools, 8 bn_bwd_reduce, 16 bn_bwd_apply) to measure what each costs the step.
+// (2 forward BN finalize + apply, 4 pools, 8 BN backward) to measure what each costs the step.
 #ifndef TBN_DIAG
 #define TBN_DIAG 0
 #endif
@@ -374,9 +476,11 @@ void plan_memory(tbn_backbone_plan* P) {
     const int K = c.stem ? P->stem_rows * P->kw : c.k * c.k * c.cin;
     tbn_conv_pick_tile(M, c.cout, K, &c.mt, &c.nt);
     size_t a = (size_t)cdiv(M, 128) * 2 * c.cout;  // worst case (mt = 1): autotune may pick any tile
-    size_t bparts = (size_t)tbn_bn_bwd_parts(M, c.cout) * 2 * c.cout;
     if (a > partial) partial = a;
-    if (bparts > partial) partial = bparts;
+    for (int k = 0; k < c.nparts; ++k) {
+      size_t bparts = (size_t)tbn_bn_bwd_parts(M, c.parts[k].cout) * 2 * c.parts[k].cout;
+      if (bparts > partial) partial = bparts;
+    }
     const int taps = c.stem ? P->stem_rows : c.k * c.k, ci = c.stem ? P->kw : c.cin;
     size_t ws = tbn_wgrad_workspace_floats(M, c.cout, ci, taps);
     if (ws > wsplit) wsplit = ws;
@@ -401,21 +505,27 @@ void plan_memory(tbn_backbone_plan* P) {
   P->partial_floats = partial;
   P->wsplit_floats = wsplit;
   P->wt_floats = wtf;
-  P->partial_off = take(TBN_BN_MAXL * partial);   // one region per member of a batched BN group
+  P->partial_off = take(TBN_BN_MAXL * partial);   // one region per member of a batched BN step
   P->wpack_off = take((size_t)64 * 7 * P->kw);
-  for (auto& c : P->convs)   // conv output / pooled conv output of the pool-after-conv layers: needed in eval too
-    if (c.post_pool) {
-      c.y_off = take(R * c.outH * c.outW * c.cout);
-      c.y2_off = take(R * c.outH * c.outW * c.cout);
-    }
+  for (auto& c : P->convs)   // raw / pooled conv output of the pool-after-conv layers: needed in eval too
+    for (int k = 0; k < c.nparts; ++k)
+      if (c.parts[k].pooled) {
+        c.parts[k].yraw_off = take(R * c.outH * c.outW * c.parts[k].cout);
+        c.parts[k].y2_off = take(R * c.outH * c.outW * c.parts[k].cout);
+      }
   P->eval_floats = off;
   // training-only regions
-  for (auto& c : P->convs)
-    if (!c.post_pool) c.y_off = take(R * c.outH * c.outW * c.cout);
+  for (auto& c : P->convs) c.y_off = take(R * c.outH * c.outW * c.cout);
   for (size_t i = 1; i < P->bufs.size(); ++i) {
     if ((int)i == P->out_buf) continue;  // gradient of the final feature map is supplied by the caller
     P->bufs[i].doff = take(R * P->bufs[i].H * P->bufs[i].W * P->bufs[i].C);
   }
+  for (auto& c : P->convs)   // BN-backward partials filled by a data-gradient epilogue: live until that layer's BN backward
+    for (int k = 0; k < c.nparts; ++k)
+      if (c.parts[k].red_src >= 0) {
+        const Buf& db = P->bufs[c.parts[k].dst_buf];
+        c.parts[k].bpart_off = take(((size_t)cdiv((int)(R * db.H * db.W), 128) + 4) * 2 * c.parts[k].cout);
+      }
   P->coef_off = take(TBN_BN_MAXL * 3 * 1024);
   P->wsplit_off = take(wsplit);
   P->wt_off = take(wtf);
@@ -484,22 +594,21 @@ int tbn_backbone_conv_info(const tbn_backbone_plan* P, int idx, tbn_conv_info* i
   TBN_REQUIRE(info != nullptr, "conv_info: null info");
   int n = 0;
   for (auto& c : P->convs) {
-    size_t w = c.w_off, ch = c.c_off;
+    size_t w = c.w_off;
     for (int i = 0; i < c.nparts; ++i) {
       if (n == idx) {
         memset(info, 0, sizeof(*info));
-        snprintf(info->name, sizeof(info->name), "%s", c.names[i].c_str());
+        snprintf(info->name, sizeof(info->name), "%s", c.parts[i].name.c_str());
         info->cin = c.cin;
-        info->cout = c.couts[i];
+        info->cout = c.parts[i].cout;
         info->ksize = c.k;
         info->stride = c.stride;
         info->pad = c.pad;
         info->weight_offset = w;
-        info->channel_offset = ch;
+        info->channel_offset = c.parts[i].c_off;
         return TBN_OK;
       }
-      w += (size_t)c.couts[i] * c.k * c.k * c.cin;
-      ch += c.couts[i];
+      w += (size_t)c.parts[i].cout * c.k * c.k * c.cin;
       ++n;
     }
   }
@@ -508,32 +617,29 @@ int tbn_backbone_conv_info(const tbn_backbone_plan* P, int idx, tbn_conv_info* i
 }
 
 // debugging / per-layer parity tests: where one conv's tensors live inside the workspace.
-// kind 0: z = relu(bn(conv)) destination slice; 1: raw conv output y (after backward: dy);
+// kind 0: z = relu(bn(conv)) destination slice; 1: BN input y (after backward: dy);
 // 2: gradient wrt z.  offset in floats (for kind 2 of the final block the gradient is external: -1).
 int tbn_backbone_tensor_info(const tbn_backbone_plan* P, const char* conv_name, int kind, long* offset, int* rows,
                              int* cols, int* ld) {
-  for (auto& c : P->convs) {
-    int col = 0;
+  for (auto& c : P->convs)
     for (int i = 0; i < c.nparts; ++i) {
-      if (c.names[i] == conv_name) {
-        const Buf& db = P->bufs[c.dst_buf[i]];
-        *rows = P->frames * c.outH * c.outW;
-        *cols = c.couts[i];
-        if (kind == 1) {
-          *offset = (long)((c.post_pool ? c.y2_off : c.y_off) + col);
-          *ld = c.cout;
-        } else if (kind == 0) {
-          *offset = (long)(db.off + c.dst_choff[i]);
-          *ld = db.C;
-        } else {
-          *offset = c.dst_buf[i] == P->out_buf ? -1 : (long)(db.doff + c.dst_choff[i]);
-          *ld = db.C;
-        }
-        return TBN_OK;
+      const Part& q = c.parts[i];
+      if (q.name != conv_name) continue;
+      const Buf& db = P->bufs[q.dst_buf];
+      *rows = P->frames * c.outH * c.outW;
+      *cols = q.cout;
+      if (kind == 1) {
+        *offset = (long)(q.pooled ? q.y2_off : c.y_off + q.col0);
+        *ld = q.pooled ? q.cout : c.cout;
+      } else if (kind == 0) {
+        *offset = (long)(db.off + q.dst_choff);
+        *ld = db.C;
+      } else {
+        *offset = q.dst_buf == P->out_buf ? -1 : (long)(db.doff + q.dst_choff);
+        *ld = db.C;
       }
-      col += c.couts[i];
+      return TBN_OK;
     }
-  }
   tbn_set_error("tensor_info: unknown conv '%s'", conv_name);
   return TBN_ERR_ARG;
 }
@@ -557,183 +663,101 @@ int tbn_backbone_out_shape(const tbn_backbone_plan* P, int* h, int* w, int* c) {
     if (rc__ != TBN_OK) return rc__; \
   } while (0)
 
-int tbn_backbone_forward(const tbn_backbone_plan* P, int training, const float* x_nchw,
-                         const tbn_backbone_params* prm, void* workspace, size_t workspace_bytes,
-                         float** features_out, void* stream) {
-  hipStream_t st = (hipStream_t)stream;
-  TBN_REQUIRE(P && x_nchw && prm && workspace && features_out, "backbone_forward: null argument");
-  TBN_REQUIRE(workspace_bytes >= tbn_backbone_workspace_bytes(P, training), "backbone_forward: workspace too small");
-  TBN_REQUIRE(((uintptr_t)workspace & 255) == 0, "backbone_forward: workspace must be 256-B aligned");
-  float* ws = (float*)workspace;
-  const int R = P->frames;
-  float* mean = ws + P->stats_off;
-  float* rstd = mean + P->chan_floats;
-  float* scale = rstd + P->chan_floats;
-  float* shift = scale + P->chan_floats;
-  float* wpack = ws + P->wpack_off;
+}  // extern "C"
 
-  if (P->s2d) {
-    TBN_TRY(tbn_launch_nchw1_to_s2d(x_nchw, ws + P->x0_off, R, P->H, P->W, st));
-    TBN_TRY(tbn_launch_pack_stem_weight_s2d(prm->weight + P->convs[0].w_off, wpack, 64, st));
+namespace {
+
+// forward-conv launch parameters of one GEMM (shared by forward and autotune); output segments are set by the caller
+void fill_fwd(const tbn_backbone_plan* P, const Conv& c, float* ws, const float* weight, int R, ConvP* pp) {
+  ConvP& p = *pp;
+  const Buf& ib = P->bufs[c.inbuf];
+  memset(&p, 0, sizeof(p));
+  p.in = ws + ib.off;
+  p.in_ld = ib.C;
+  p.N = R;
+  p.H = c.inH;
+  p.W = c.inW;
+  p.OH = c.outH;
+  p.OW = c.outW;
+  p.Cout = c.cout;
+  p.stride = c.stride;
+  p.pad = c.pad;
+  p.up = 1;
+  p.M = R * c.outH * c.outW;
+  p.bias = nullptr;  // training: cancels in the batch-stat BN (finalize adds it to running_mean); eval: folded into shift
+  p.alg_flops = 2.0 * p.M * (double)c.cout * c.k * c.k * c.cin;
+  if (c.stem) {
+    p.wt = ws + P->wpack_off;
+    p.Cin = P->kw;
+    p.R = P->stem_rows;
+    p.S = 1;
+    p.K = P->stem_rows * P->kw;
+    p.cp = P->cp;
+    p.H = P->stem_H;          // s2d: the 4-row / stride-1 conv on the space-to-depth image
+    p.W = P->stem_W;
+    p.stride = P->stem_stride;
+    p.pad = P->stem_pad;
   } else {
-    TBN_TRY(tbn_launch_nchw_to_nhwc_pad(x_nchw, ws + P->x0_off, R, P->cin0, P->H, P->W, P->cp, st));
-    TBN_TRY(tbn_launch_pack_stem_weight(prm->weight + P->convs[0].w_off, wpack, 64, P->cin0, P->cp, P->kw, st));
+    p.wt = weight + c.w_off;
+    p.Cin = c.cin;
+    p.R = p.S = c.k;
+    p.K = c.k * c.k * c.cin;
   }
-  if (!training)
-    TBN_TRY(tbn_launch_bn_fold(prm->gamma, prm->beta, prm->running_mean, prm->running_var, prm->bias, prm->eps, scale,
-                               shift, (int)P->chan_floats, st));
+  p.stages = c.stages;
+}
 
-  BnFwdBatch fwd_batch;
-  memset(&fwd_batch, 0, sizeof(fwd_batch));
-  for (const Op& o : P->ops) {
-    if (o.kind == 0) {
-      const Conv& c = P->convs[o.idx];
-      const Buf& ib = P->bufs[c.inbuf];
-      ConvP p;
-      memset(&p, 0, sizeof(p));
-      p.in = ws + ib.off;
-      p.in_ld = ib.C;
-      p.N = R;
-      p.H = c.inH;
-      p.W = c.inW;
-      p.OH = c.outH;
-      p.OW = c.outW;
-      p.Cout = c.cout;
-      p.stride = c.stride;
-      p.pad = c.pad;
-      p.up = 1;
-      p.M = R * c.outH * c.outW;
-      p.bias = nullptr;  // training: cancels in the batch-stat BN (finalize adds it to running_mean); eval: folded into shift
-      p.alg_flops = 2.0 * p.M * (double)c.cout * c.k * c.k * c.cin;
-      if (c.stem) {
-        p.wt = wpack;
-        p.Cin = P->kw;
-        p.R = P->stem_rows;
-        p.S = 1;
-        p.K = P->stem_rows * P->kw;
-        p.cp = P->cp;
-        p.H = P->stem_H;          // s2d: the 4-row / stride-1 conv on the space-to-depth image
-        p.W = P->stem_W;
-        p.stride = P->stem_stride;
-        p.pad = P->stem_pad;
-      } else {
-        p.wt = prm->weight + c.w_off;
-        p.Cin = c.cin;
-        p.R = p.S = c.k;
-        p.K = c.k * c.k * c.cin;
-      }
-      Seg zs[3];
-      int col = 0;
-      for (int i = 0; i < c.nparts; ++i) {
-        const Buf& db = P->bufs[c.dst_buf[i]];
-        zs[i].ptr = ws + db.off + c.dst_choff[i];
-        zs[i].ld = db.C;
-        zs[i].col_begin = col;
-        col += c.couts[i];
-      }
-      tbn_prof_label(("fwd " + c.names[c.nparts - 1]).c_str());
-      // members of a batched BN group (training) write their statistics partials into their own scratch region
-      const bool grouped = training && c.group >= 0;
-      float* part = ws + P->partial_off + (grouped ? (size_t)c.group_pos * P->partial_floats : 0);
-      float* bn_in = ws + c.y_off;     // BN input (post_pool: the pooled conv output)
-      int nparts = 0;
-      if (c.post_pool) {
-        // bias-free 1x1 conv on the block input -> 3x3 average of its few output channels -> BN (+ReLU) -> concat
-        float* u_raw = ws + c.y_off;
-        bn_in = ws + c.y2_off;
-        p.mode = CONV_EPI_PLAIN;
-        p.nseg = 1;
-        p.seg[0].ptr = u_raw;
-        p.seg[0].ld = c.cout;
-        p.seg[0].col_begin = 0;
-        p.stages = c.stages;
-        TBN_TRY(tbn_launch_conv(p, false, c.mt, c.nt, st));
-        if (!diag_skip(4))
-          TBN_TRY(tbn_launch_avgpool3_fwd(u_raw, c.cout, bn_in, c.cout, R, c.outH, c.outW, c.cout, 0, st));
-        if (training) TBN_TRY(tbn_launch_bn_stats(bn_in, c.cout, p.M, c.cout, part, &nparts, st));
-      } else if (training) {
-        p.mode = CONV_EPI_STATS;
-        p.nseg = 1;
-        p.seg[0].ptr = bn_in;
-        p.seg[0].ld = c.cout;
-        p.seg[0].col_begin = 0;
-        p.stat_partial = part;
-        p.stages = c.stages;
-        TBN_TRY(tbn_launch_conv(p, c.stem, c.mt, c.nt, st));
-        nparts = cdiv(p.M, 128 * c.mt);
-      }
-      if (grouped) {
-        BnFwdLayer& L = fwd_batch.l[c.group_pos];
-        L.y = bn_in;
-        L.P = p.M;
-        L.C = c.cout;
-        L.partial = part;
-        L.nparts = nparts;
-        L.gamma = prm->gamma + c.c_off;
-        L.beta = prm->beta + c.c_off;
-        L.conv_bias = prm->bias + c.c_off;
-        L.running_mean = prm->running_mean + c.c_off;
-        L.running_var = prm->running_var + c.c_off;
-        L.save_mean = mean + c.c_off;
-        L.save_rstd = rstd + c.c_off;
-        L.scale = scale + c.c_off;
-        L.shift = shift + c.c_off;
-        L.nseg = c.nparts;
-        for (int i = 0; i < c.nparts; ++i) L.seg[i] = zs[i];
-        if (c.group_pos == c.group_size - 1) {   // last member issued: one finalize + one apply for the group
-          fwd_batch.n = c.group_size;
-          fwd_batch.momentum = prm->momentum;
-          fwd_batch.eps = prm->eps;
-          if (!diag_skip(3)) TBN_TRY(tbn_launch_bn_fwd_multi(fwd_batch, st));
-        }
-      } else if (training) {
-        if (!diag_skip(1))
-          TBN_TRY(tbn_launch_bn_finalize(part, nparts, p.M, c.cout, prm->gamma + c.c_off, prm->beta + c.c_off,
-                                         prm->bias + c.c_off, prm->running_mean + c.c_off, prm->running_var + c.c_off,
-                                         prm->momentum, prm->eps, mean + c.c_off, rstd + c.c_off, scale + c.c_off,
-                                         shift + c.c_off, st));
-        if (c.fuse_pool >= 0) {
-          const Pool& q = P->pools[c.fuse_pool];
-          const Buf& ob = P->bufs[q.outbuf];
-          if (!diag_skip(2))
-            TBN_TRY(tbn_launch_bn_apply_maxpool(bn_in, (int)R, c.outH, c.outW, c.cout, scale + c.c_off, shift + c.c_off,
-                                                ws + ob.off + q.out_choff, ob.C, (uint8_t*)workspace + q.argmax_off,
-                                                ob.H, ob.W, q.stride, q.pad, st));
-        } else if (!diag_skip(2)) {
-          TBN_TRY(tbn_launch_bn_apply(bn_in, p.M, c.cout, scale + c.c_off, shift + c.c_off, zs, c.nparts, st));
-        }
-      } else if (c.post_pool) {
-        if (!diag_skip(2))   // eval: scale / shift are the folded running statistics (conv bias included)
-          TBN_TRY(tbn_launch_bn_apply(bn_in, p.M, c.cout, scale + c.c_off, shift + c.c_off, zs, c.nparts, st));
-      } else {
-        p.mode = CONV_EPI_EVAL;
-        p.scale = scale + c.c_off;
-        p.shift = shift + c.c_off;
-        p.nseg = c.nparts;
-        for (int i = 0; i < c.nparts; ++i) p.seg[i] = zs[i];
-        p.stages = c.stages;
-        TBN_TRY(tbn_launch_conv(p, c.stem, c.mt, c.nt, st));
-      }
-    } else {
-      const Pool& q = P->pools[o.idx];
-      const Buf& ib = P->bufs[q.inbuf];
-      const Buf& ob = P->bufs[q.outbuf];
-      if (training && q.fused) continue;  // ran inside the producer's BN apply
-      if (q.kind == 0) {
-        if (!diag_skip(4)) TBN_TRY(tbn_launch_avgpool3_fwd(ws + ib.off, ib.C, ws + ob.off + q.out_choff, ob.C, R, ib.H, ib.W, ib.C, 0, st));
-      } else {
-        uint8_t* am = training ? (uint8_t*)workspace + q.argmax_off : nullptr;
-        if (!diag_skip(4)) TBN_TRY(tbn_launch_maxpool_fwd(ws + ib.off, ib.C, ws + ob.off + q.out_choff, ob.C, am, R, ib.H, ib.W, ib.C,
-                                       ob.H, ob.W, q.stride, q.pad, st));
-      }
-    }
+// data-gradient launch parameters of one GEMM: conv of dy with flipped / transposed weights (parity phases for
+// stride 2), plus the fused BN-backward reduce of the layers whose dz it finishes
+void fill_dgrad(const tbn_backbone_plan* P, const Conv& c, float* ws, int R, ConvP* pp) {
+  ConvP& p = *pp;
+  const Buf& ib = P->bufs[c.inbuf];
+  memset(&p, 0, sizeof(p));
+  p.in = ws + c.y_off;
+  p.in_ld = c.cout;
+  p.wt = ws + P->wt_off + c.w_off;
+  p.N = R;
+  p.H = c.outH;
+  p.W = c.outW;
+  p.OH = c.inH;
+  p.OW = c.inW;
+  p.Cin = c.cout;
+  p.Cout = c.cin;
+  p.R = p.S = c.k;
+  p.stride = 1;
+  p.pad = c.k - 1 - c.pad;
+  p.up = c.stride;      // stride-2 layers: the four parity phases in one launch
+  p.M = R * c.inH * c.inW;
+  p.K = c.k * c.k * c.cout;
+  p.alg_flops = 2.0 * R * c.outH * c.outW * (double)c.cout * c.k * c.k * c.cin;  // = forward count (zero-insertion not counted)
+  p.mode = CONV_EPI_PLAIN;
+  p.flags = c.dgrad_accum ? CONV_FLAG_ACCUM : 0;
+  p.nseg = 1;
+  p.seg[0].ptr = ws + ib.doff;
+  p.seg[0].ld = ib.C;
+  p.seg[0].col_begin = 0;
+  p.stages = c.d_stages;
+  p.nred = c.nred;
+  p.red_chan = (int)P->chan_floats;
+  for (int k = 0; k < c.nred; ++k) {
+    const Conv& pc = P->convs[c.red_conv[k]];
+    const Part& q = pc.parts[c.red_part[k]];
+    RedSeg& r = p.red[k];
+    r.y = q.pooled ? ws + q.y2_off : ws + pc.y_off + q.col0;
+    r.y_ld = q.pooled ? q.cout : pc.cout;
+    r.partial = ws + q.bpart_off;
+    r.stats = ws + P->stats_off;
+    r.col_begin = q.dst_choff;
+    r.C = q.cout;
+    r.c_off = (int)q.c_off;
   }
-  *features_out = ws + P->bufs[P->out_buf].off;
-  return TBN_OK;
+  if (c.nred > 0 && p.red[0].col_begin != 0) {
+    // columns in front of the first BN layer (none in this graph) would need a leading empty segment
+    p.nred = 0;
+  }
 }
 
 // weight-gradient launch parameters of one conv (shared by backward and autotune)
-static void fill_wgrad(const tbn_backbone_plan* P, const Conv& c, float* ws, int R, WgradP* wp) {
+void fill_wgrad(const tbn_backbone_plan* P, const Conv& c, float* ws, int R, WgradP* wp) {
   const Buf& ib = P->bufs[c.inbuf];
   memset(wp, 0, sizeof(*wp));
   wp->dy = ws + c.y_off;
@@ -769,10 +793,191 @@ static void fill_wgrad(const tbn_backbone_plan* P, const Conv& c, float* ws, int
   }
 }
 
+// joins the aux (weight-gradient) stream into the launch stream on every exit path of tbn_backbone_backward
+struct AuxJoin {
+  hipStream_t st, aux;
+  hipEvent_t ev;
+  bool forked = false;
+  ~AuxJoin() {
+    if (aux != nullptr && forked) {
+      (void)hipEventRecord(ev, aux);
+      (void)hipStreamWaitEvent(st, ev, 0);
+    }
+  }
+};
+
+}  // namespace
+
+extern "C" {
+
+int tbn_backbone_forward(const tbn_backbone_plan* P, int training, const float* x_nchw,
+                         const tbn_backbone_params* prm, void* workspace, size_t workspace_bytes,
+                         float** features_out, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  TBN_REQUIRE(P && x_nchw && prm && workspace && features_out, "backbone_forward: null argument");
+  TBN_REQUIRE(workspace_bytes >= tbn_backbone_workspace_bytes(P, training), "backbone_forward: workspace too small");
+  TBN_REQUIRE(((uintptr_t)workspace & 255) == 0, "backbone_forward: workspace must be 256-B aligned");
+  float* ws = (float*)workspace;
+  const int R = P->frames;
+  float* mean = ws + P->stats_off;
+  float* rstd = mean + P->chan_floats;
+  float* scale = rstd + P->chan_floats;
+  float* shift = scale + P->chan_floats;
+  float* wpack = ws + P->wpack_off;
+
+  if (P->s2d) {
+    TBN_TRY(tbn_launch_nchw1_to_s2d(x_nchw, ws + P->x0_off, R, P->H, P->W, st));
+    TBN_TRY(tbn_launch_pack_stem_weight_s2d(prm->weight + P->convs[0].w_off, wpack, 64, st));
+  } else {
+    TBN_TRY(tbn_launch_nchw_to_nhwc_pad(x_nchw, ws + P->x0_off, R, P->cin0, P->H, P->W, P->cp, st));
+    TBN_TRY(tbn_launch_pack_stem_weight(prm->weight + P->convs[0].w_off, wpack, 64, P->cin0, P->cp, P->kw, st));
+  }
+  if (!training)
+    TBN_TRY(tbn_launch_bn_fold(prm->gamma, prm->beta, prm->running_mean, prm->running_var, prm->bias, prm->eps, scale,
+                               shift, (int)P->chan_floats, st));
+
+  for (const Op& o : P->ops) {
+    if (o.kind == OP_CONV) {
+      const Conv& c = P->convs[o.idx];
+      ConvP p;
+      fill_fwd(P, c, ws, prm->weight, R, &p);
+      tbn_prof_label(("fwd " + c.parts[c.nparts - 1].name).c_str());
+      if (training) {
+        // raw (bias-free) conv output of every part into the layer's y buffer + per-channel statistics partials
+        p.mode = CONV_EPI_STATS;
+        p.nseg = 1;
+        p.seg[0].ptr = ws + c.y_off;
+        p.seg[0].ld = c.cout;
+        p.seg[0].col_begin = 0;
+        p.stat_partial = ws + P->partial_off + (size_t)c.slot * P->partial_floats;
+      } else {
+        // eval: running-stat BN + ReLU folded into the epilogue, straight into the concat slices; a pooled part
+        // (pool_proj) leaves the bare conv output for its average pool
+        p.mode = CONV_EPI_EVAL;
+        p.scale = scale + c.c_off;
+        p.shift = shift + c.c_off;
+        p.nseg = c.nparts;
+        for (int i = 0; i < c.nparts; ++i) {
+          const Part& q = c.parts[i];
+          const Buf& db = P->bufs[q.dst_buf];
+          p.seg[i].ptr = q.pooled ? ws + q.yraw_off : ws + db.off + q.dst_choff;
+          p.seg[i].ld = q.pooled ? q.cout : db.C;
+          p.seg[i].col_begin = q.col0;
+          if (q.pooled) p.raw_seg1 = i + 1;
+        }
+      }
+      TBN_TRY(tbn_launch_conv(p, c.stem, c.mt, c.nt, st));
+    } else if (o.kind == OP_PREPOOL) {
+      // pool_proj: 3x3 average of its conv output columns -> BN input (+ its batch statistics in training)
+      const Conv& c = P->convs[o.idx];
+      const Part& q = c.parts[o.part];
+      const int M = R * c.outH * c.outW;
+      const float* src = training ? ws + c.y_off + q.col0 : ws + q.yraw_off;
+      const int src_ld = training ? c.cout : q.cout;
+      if (!diag_skip(4)) TBN_TRY(tbn_launch_avgpool3_fwd(src, src_ld, ws + q.y2_off, q.cout, R, c.outH, c.outW, q.cout, 0, st));
+      if (training) {
+        int nparts = 0;
+        TBN_TRY(tbn_launch_bn_stats(ws + q.y2_off, q.cout, M, q.cout,
+                                    ws + P->partial_off + (size_t)q.slot * P->partial_floats, &nparts, st));
+      }
+    } else if (o.kind == OP_BN) {
+      const BnStep& s = P->bns[o.idx];
+      if (!training) {
+        // only a pooled part still needs its (folded) BN + ReLU
+        for (int k = 0; k < s.n; ++k) {
+          const Conv& c = P->convs[s.conv[k]];
+          const Part& q = c.parts[s.part[k]];
+          if (!q.pooled) continue;
+          const Buf& db = P->bufs[q.dst_buf];
+          Seg z;
+          z.ptr = ws + db.off + q.dst_choff;
+          z.ld = db.C;
+          z.col_begin = 0;
+          if (!diag_skip(2))
+            TBN_TRY(tbn_launch_bn_apply(ws + q.y2_off, R * c.outH * c.outW, q.cout, scale + q.c_off, shift + q.c_off, &z, 1, st));
+        }
+        continue;
+      }
+      const Conv& c0 = P->convs[s.conv[0]];
+      if (s.n == 1 && c0.fuse_pool >= 0) {
+        // conv -> BN -> ReLU -> max pool: the pool runs inside the BN apply (z is never written)
+        const Part& q = c0.parts[0];
+        const int M = R * c0.outH * c0.outW;
+        const Pool& pl = P->pools[c0.fuse_pool];
+        const Buf& ob = P->bufs[pl.outbuf];
+        if (!diag_skip(2)) {
+          TBN_TRY(tbn_launch_bn_finalize(ws + P->partial_off + (size_t)c0.slot * P->partial_floats, cdiv(M, 128 * c0.mt), M,
+                                         q.cout, prm->gamma + q.c_off, prm->beta + q.c_off, prm->bias + q.c_off,
+                                         prm->running_mean + q.c_off, prm->running_var + q.c_off, prm->momentum, prm->eps,
+                                         mean + q.c_off, rstd + q.c_off, scale + q.c_off, shift + q.c_off, st));
+          TBN_TRY(tbn_launch_bn_apply_maxpool(ws + c0.y_off, (int)R, c0.outH, c0.outW, q.cout, scale + q.c_off,
+                                              shift + q.c_off, ws + ob.off + pl.out_choff, ob.C,
+                                              (uint8_t*)workspace + pl.argmax_off, ob.H, ob.W, pl.stride, pl.pad, st));
+        }
+        continue;
+      }
+      BnFwdBatch fb;
+      memset(&fb, 0, sizeof(fb));
+      fb.n = s.n;
+      fb.momentum = prm->momentum;
+      fb.eps = prm->eps;
+      for (int k = 0; k < s.n; ++k) {
+        const Conv& c = P->convs[s.conv[k]];
+        const Part& q = c.parts[s.part[k]];
+        const Buf& db = P->bufs[q.dst_buf];
+        const int M = R * c.outH * c.outW;
+        BnFwdLayer& L = fb.l[k];
+        L.P = M;
+        L.C = q.cout;
+        if (q.pooled) {
+          L.y = ws + q.y2_off;
+          L.y_ld = q.cout;
+          L.partial = ws + P->partial_off + (size_t)q.slot * P->partial_floats;
+          L.pld = q.cout;
+          L.nparts = tbn_bn_stats_parts(M, q.cout);
+        } else {
+          L.y = ws + c.y_off + q.col0;
+          L.y_ld = c.cout;
+          L.partial = ws + P->partial_off + (size_t)c.slot * P->partial_floats + q.col0;
+          L.pld = c.cout;
+          L.nparts = cdiv(M, 128 * c.mt);
+        }
+        L.gamma = prm->gamma + q.c_off;
+        L.beta = prm->beta + q.c_off;
+        L.conv_bias = prm->bias + q.c_off;
+        L.running_mean = prm->running_mean + q.c_off;
+        L.running_var = prm->running_var + q.c_off;
+        L.save_mean = mean + q.c_off;
+        L.save_rstd = rstd + q.c_off;
+        L.scale = scale + q.c_off;
+        L.shift = shift + q.c_off;
+        L.nseg = 1;
+        L.seg[0].ptr = ws + db.off + q.dst_choff;
+        L.seg[0].ld = db.C;
+        L.seg[0].col_begin = 0;
+      }
+      if (!diag_skip(2)) TBN_TRY(tbn_launch_bn_fwd_multi(fb, st));
+    } else {
+      const Pool& q = P->pools[o.idx];
+      const Buf& ib = P->bufs[q.inbuf];
+      const Buf& ob = P->bufs[q.outbuf];
+      if (training && q.fused) continue;  // ran inside the producer's BN apply
+      if (q.kind == 0) {
+        if (!diag_skip(4)) TBN_TRY(tbn_launch_avgpool3_fwd(ws + ib.off, ib.C, ws + ob.off + q.out_choff, ob.C, R, ib.H, ib.W, ib.C, 0, st));
+      } else {
+        uint8_t* am = training ? (uint8_t*)workspace + q.argmax_off : nullptr;
+        if (!diag_skip(4)) TBN_TRY(tbn_launch_maxpool_fwd(ws + ib.off, ib.C, ws + ob.off + q.out_choff, ob.C, am, R, ib.H, ib.W, ib.C,
+                                       ob.H, ob.W, q.stride, q.pad, st));
+      }
+    }
+  }
+  *features_out = ws + P->bufs[P->out_buf].off;
+  return TBN_OK;
+}
 
 // One-time tile autotuning: times every (MT, NT) tile of the forward and data-gradient implicit GEMM
 // of each layer on the real shapes (2 launches each, hipEvents) and stores the fastest in the plan.
-// Synchronises the stream (the only entry point that does); activations in `workspace` are clobbered.
+// Synchronises the device (the only entry point that does); activations in `workspace` are clobbered.
 int tbn_backbone_autotune(tbn_backbone_plan* P, int training, const tbn_backbone_params* prm, void* workspace,
                           size_t workspace_bytes, void* stream) {
   hipStream_t st = (hipStream_t)stream;
@@ -787,45 +992,17 @@ int tbn_backbone_autotune(tbn_backbone_plan* P, int training, const tbn_backbone
     tbn_set_error("autotune: hipEventCreate failed");
     return TBN_ERR_LAUNCH;
   }
+  // candidates are timed one at a time: whatever other streams still run (the other modality backbones of a first
+  // step) would make the choice depend on what happened to overlap -> drain the device first
+  (void)hipDeviceSynchronize();
   int rc = TBN_OK;
   for (auto& c : P->convs) {
-    const Buf& ib = P->bufs[c.inbuf];
     for (int pass = 0; pass < 2 && rc == TBN_OK; ++pass) {  // 0: forward, 1: data gradient
       if (pass == 1 && (!training || !c.need_dgrad)) continue;
       ConvP p;
-      memset(&p, 0, sizeof(p));
-      p.N = R;
-      p.up = 1;
-      p.nseg = 1;
       if (pass == 0) {
-        p.in = ws + ib.off;
-        p.in_ld = ib.C;
-        p.H = c.inH;
-        p.W = c.inW;
-        p.OH = c.outH;
-        p.OW = c.outW;
-        p.Cout = c.cout;
-        p.stride = c.stride;
-        p.pad = c.pad;
-        p.M = R * c.outH * c.outW;
-        p.bias = nullptr;
-        if (c.stem) {
-          p.wt = ws + P->wpack_off;
-          p.Cin = P->kw;
-          p.R = P->stem_rows;
-          p.S = 1;
-          p.K = P->stem_rows * P->kw;
-          p.cp = P->cp;
-          p.H = P->stem_H;          // s2d: the 4-row / stride-1 conv on the space-to-depth image
-          p.W = P->stem_W;
-          p.stride = P->stem_stride;
-          p.pad = P->stem_pad;
-        } else {
-          p.wt = prm->weight + c.w_off;
-          p.Cin = c.cin;
-          p.R = p.S = c.k;
-          p.K = c.k * c.k * c.cin;
-        }
+        fill_fwd(P, c, ws, prm->weight, R, &p);
+        p.nseg = 1;
         p.mode = training ? CONV_EPI_STATS : CONV_EPI_EVAL;
         p.scale = scale + c.c_off;
         p.shift = shift + c.c_off;
@@ -835,31 +1012,13 @@ int tbn_backbone_autotune(tbn_backbone_plan* P, int training, const tbn_backbone
           p.seg[0].ptr = ws + c.y_off;
           p.seg[0].ld = c.cout;
         } else {
-          const Buf& db = P->bufs[c.dst_buf[0]];
-          p.seg[0].ptr = ws + db.off + c.dst_choff[0];
+          if (c.nparts > 1) continue;   // eval tuning on single-part layers only keeps all writes in range
+          const Buf& db = P->bufs[c.parts[0].dst_buf];
+          p.seg[0].ptr = ws + db.off + c.parts[0].dst_choff;
           p.seg[0].ld = db.C;
-          p.Cout = c.couts[0];  // eval tuning on the first fused part only keeps all writes in range
-          if (c.nparts > 1) continue;
         }
       } else {
-        p.in = ws + c.y_off;
-        p.in_ld = c.cout;
-        p.wt = ws + P->wt_off + c.w_off;
-        p.H = c.outH;
-        p.W = c.outW;
-        p.OH = c.inH;
-        p.OW = c.inW;
-        p.Cin = c.cout;
-        p.Cout = c.cin;
-        p.R = p.S = c.k;
-        p.stride = 1;
-        p.pad = c.k - 1 - c.pad;
-        p.up = c.stride;      // stride-2 layers: the four parity phases in one launch
-        p.M = R * c.inH * c.inW;
-        p.K = c.k * c.k * c.cout;
-        p.mode = CONV_EPI_PLAIN;
-        p.seg[0].ptr = ws + ib.doff;
-        p.seg[0].ld = ib.C;
+        fill_dgrad(P, c, ws, R, &p);
       }
       // fastest of the candidates in isolation.  (Measured alternatives that lost: preferring the largest tile
       // within 3-15 % of the fastest -- monotonically slower steps; autotuning the weight-gradient tile the same
@@ -905,10 +1064,14 @@ int tbn_backbone_autotune(tbn_backbone_plan* P, int training, const tbn_backbone
 
 int tbn_backbone_backward(const tbn_backbone_plan* P, const float* dfeatures, const tbn_backbone_params* prm,
                           const tbn_backbone_grads* g, void* workspace, size_t workspace_bytes, void* stream) {
+  TBN_REQUIRE(P && dfeatures && prm && g && workspace, "backbone_backward: null argument");
+  TBN_REQUIRE(g->dweight && g->dbias, "backbone_backward: dweight/dbias required");
+  TBN_REQUIRE(workspace_bytes >= P->total_bytes_train, "backbone_backward: workspace too small");
   hipStream_t st = (hipStream_t)stream;
   hipStream_t aux = (hipStream_t)g->aux_stream;
   tbn_backbone_plan* PM = const_cast<tbn_backbone_plan*>(P);  // event pool only
-  if (aux != nullptr && aux != st && PM->n_ev == 0) {
+  if (aux == st) aux = nullptr;
+  if (aux != nullptr && PM->n_ev == 0) {
     for (int i = 0; i < 8; ++i) {
       if (hipEventCreateWithFlags(&PM->ev[i], hipEventDisableTiming) != hipSuccess) {
         tbn_set_error("backbone_backward: hipEventCreate failed");
@@ -917,11 +1080,11 @@ int tbn_backbone_backward(const tbn_backbone_plan* P, const float* dfeatures, co
       PM->n_ev = i + 1;
     }
   }
-  if (aux == st) aux = nullptr;
+  TBN_REQUIRE(aux == nullptr || PM->n_ev == 8, "backbone_backward: event pool incomplete");
+  // events 0..6 fork (launch stream -> aux), event 7 is the join: whatever path leaves this function, the aux stream
+  // is joined back (a fork left open would also break hipGraph capture of a step)
+  AuxJoin join{st, aux, aux != nullptr ? PM->ev[7] : nullptr};
   int ev_next = 0;
-  TBN_REQUIRE(P && dfeatures && prm && g && workspace, "backbone_backward: null argument");
-  TBN_REQUIRE(g->dweight && g->dbias, "backbone_backward: dweight/dbias required");
-  TBN_REQUIRE(workspace_bytes >= P->total_bytes_train, "backbone_backward: workspace too small");
   float* ws = (float*)workspace;
   const int R = P->frames;
   float* mean = ws + P->stats_off;
@@ -937,7 +1100,7 @@ int tbn_backbone_backward(const tbn_backbone_plan* P, const float* dfeatures, co
   TBN_TRY(tbn_launch_weight_flip_transpose_all(prm->weight, ws + P->wt_off, P->flip, st));
   for (int oi = (int)P->ops.size() - 1; oi >= 0; --oi) {
     const Op& o = P->ops[oi];
-    if (o.kind == 1) {
+    if (o.kind == OP_POOL) {
       const Pool& q = P->pools[o.idx];
       const Buf& ib = P->bufs[q.inbuf];
       const Buf& ob = P->bufs[q.outbuf];
@@ -953,97 +1116,89 @@ int tbn_backbone_backward(const tbn_backbone_plan* P, const float* dfeatures, co
       }
       continue;
     }
-    const Conv& c = P->convs[o.idx];
-    const Buf& ib = P->bufs[c.inbuf];
-    const int M = R * c.outH * c.outW;
-    float* const dconv = ws + c.y_off;                         // gradient of the conv output, read by wgrad / dgrad
-    float* y = c.post_pool ? ws + c.y2_off : dconv;             // BN input; becomes dy in place
-    CSeg dz[3];
-    int col = 0;
-    for (int i = 0; i < c.nparts; ++i) {
-      const Buf& db = P->bufs[c.dst_buf[i]];
-      dz[i].ptr = dptr(c.dst_buf[i]) + c.dst_choff[i];
-      dz[i].ld = db.C;
-      dz[i].col_begin = col;
-      col += c.couts[i];
+    if (o.kind == OP_PREPOOL) {
+      // the 3x3 average is self-adjoint: d(conv output columns) = avg_pool(d(pooled)), written next to the dy of the
+      // other parts of the fused GEMM
+      const Conv& c = P->convs[o.idx];
+      const Part& q = c.parts[o.part];
+      if (!diag_skip(4))
+        TBN_TRY(tbn_launch_avgpool3_fwd(ws + q.y2_off, q.cout, ws + c.y_off + q.col0, c.cout, R, c.outH, c.outW, q.cout, 0, st));
+      continue;
     }
-    const bool bn_grad = g->dgamma && g->dbeta && (g->bn_grad_layers == 2 || (g->bn_grad_layers == 1 && o.idx == 0));
-    if (c.group >= 0) {
-      // batched BN backward of the whole group, issued when the reverse walk reaches its LAST member: the gradients
-      // wrt every member's BN output exist by then (concat gradient, or the data gradient of double_3x3_2)
-      if (c.group_pos == c.group_size - 1) {
-        BnBwdBatch bb;
-        memset(&bb, 0, sizeof(bb));
-        bb.n = c.group_size;
-        for (int k = 0; k < c.group_size; ++k) {
-          const Conv& m = P->convs[o.idx - (c.group_size - 1 - k)];   // members are consecutive convs
-          BnBwdLayer& L = bb.l[m.group_pos];
-          int mc = 0;
-          for (int i = 0; i < m.nparts; ++i) {
-            const Buf& db = P->bufs[m.dst_buf[i]];
-            L.dz[i].ptr = dptr(m.dst_buf[i]) + m.dst_choff[i];
-            L.dz[i].ld = db.C;
-            L.dz[i].col_begin = mc;
-            mc += m.couts[i];
-          }
-          L.nseg = m.nparts;
-          L.y = L.dy = m.post_pool ? ws + m.y2_off : ws + m.y_off;
-          L.P = R * m.outH * m.outW;
-          L.C = m.cout;
-          L.scale = scale + m.c_off;
-          L.shift = shift + m.c_off;
-          L.mean = mean + m.c_off;
-          L.rstd = rstd + m.c_off;
-          L.partial = partial + (size_t)m.group_pos * P->partial_floats;
-          L.coef = coef + (size_t)m.group_pos * 3 * 1024;
-          const bool mg = g->dgamma && g->dbeta && g->bn_grad_layers == 2;   // members are never the first layer
-          L.dgamma = mg ? g->dgamma + m.c_off : nullptr;
-          L.dbeta = mg ? g->dbeta + m.c_off : nullptr;
-          L.dbias = g->dbias + m.c_off;
+    if (o.kind == OP_BN) {
+      const BnStep& s = P->bns[o.idx];
+      const Conv& c0 = P->convs[s.conv[0]];
+      if (s.n == 1 && c0.fuse_pool >= 0) {
+        const Part& q = c0.parts[0];
+        const int M = R * c0.outH * c0.outW;
+        const Pool& pl = P->pools[c0.fuse_pool];
+        const Buf& ob = P->bufs[pl.outbuf];
+        const float* dpool = dptr(pl.outbuf) + pl.out_choff;
+        const uint8_t* am = (const uint8_t*)workspace + pl.argmax_off;
+        float* y = ws + c0.y_off;
+        const bool bn_grad = g->dgamma && g->dbeta && (g->bn_grad_layers == 2 || (g->bn_grad_layers == 1 && s.conv[0] == 0));
+        if (!diag_skip(8)) {
+          TBN_TRY(tbn_launch_bn_bwd_reduce_pooled(dpool, ob.C, am, R, c0.outH, c0.outW, ob.H, ob.W, pl.stride, pl.pad, y,
+                                                  q.cout, scale + q.c_off, shift + q.c_off, mean + q.c_off,
+                                                  rstd + q.c_off, partial, st));
+          TBN_TRY(tbn_launch_bn_bwd_finalize(partial, tbn_bn_bwd_parts(M, q.cout), M, q.cout, scale + q.c_off,
+                                             mean + q.c_off, rstd + q.c_off, coef, bn_grad ? g->dgamma + q.c_off : nullptr,
+                                             bn_grad ? g->dbeta + q.c_off : nullptr, g->dbias + q.c_off, st));
+          TBN_TRY(tbn_launch_bn_bwd_apply_pooled(dpool, ob.C, am, R, c0.outH, c0.outW, ob.H, ob.W, pl.stride, pl.pad, y,
+                                                 q.cout, scale + q.c_off, shift + q.c_off, coef, y, st));
         }
-        if (!diag_skip(27)) TBN_TRY(tbn_launch_bn_bwd_multi(bb, st));
+        continue;
       }
-    } else {
-    if (c.fuse_pool >= 0) {
-      const Pool& q = P->pools[c.fuse_pool];
-      const Buf& ob = P->bufs[q.outbuf];
-      const float* dpool = dptr(q.outbuf) + q.out_choff;
-      const uint8_t* am = (const uint8_t*)workspace + q.argmax_off;
-      if (!diag_skip(8))
-        TBN_TRY(tbn_launch_bn_bwd_reduce_pooled(dpool, ob.C, am, R, c.outH, c.outW, ob.H, ob.W, q.stride, q.pad, y,
-                                                c.cout, scale + c.c_off, shift + c.c_off, mean + c.c_off,
-                                                rstd + c.c_off, partial, st));
-    } else if (!diag_skip(8)) {
-      TBN_TRY(tbn_launch_bn_bwd_reduce(dz, c.nparts, y, M, c.cout, scale + c.c_off, shift + c.c_off, mean + c.c_off,
-                                       rstd + c.c_off, partial, st));
+      BnBwdBatch bb;
+      memset(&bb, 0, sizeof(bb));
+      bb.n = s.n;
+      for (int k = 0; k < s.n; ++k) {
+        const Conv& c = P->convs[s.conv[k]];
+        const Part& q = c.parts[s.part[k]];
+        const Buf& db = P->bufs[q.dst_buf];
+        BnBwdLayer& L = bb.l[k];
+        L.nseg = 1;
+        L.dz[0].ptr = dptr(q.dst_buf) + q.dst_choff;
+        L.dz[0].ld = db.C;
+        L.dz[0].col_begin = 0;
+        L.y = L.dy = q.pooled ? ws + q.y2_off : ws + c.y_off + q.col0;
+        L.y_ld = q.pooled ? q.cout : c.cout;
+        L.P = R * c.outH * c.outW;
+        L.C = q.cout;
+        L.scale = scale + q.c_off;
+        L.shift = shift + q.c_off;
+        L.mean = mean + q.c_off;
+        L.rstd = rstd + q.c_off;
+        if (q.red_src >= 0) {
+          // S1 / S2 partials were formed by the data-gradient epilogue that finished dz (conv RedSeg)
+          const Conv& f = P->convs[q.red_src];
+          L.partial = ws + q.bpart_off;
+          L.ext_parts = tbn_conv_red_rows(R, f.inH, f.inW, f.stride, f.d_mt);
+        } else {
+          L.partial = partial + (size_t)k * P->partial_floats;
+          L.ext_parts = 0;
+        }
+        L.coef = coef + (size_t)k * 3 * 1024;
+        const bool first = (s.conv[k] == 0);
+        const bool bg = g->dgamma && g->dbeta && (g->bn_grad_layers == 2 || (g->bn_grad_layers == 1 && first));
+        L.dgamma = bg ? g->dgamma + q.c_off : nullptr;
+        L.dbeta = bg ? g->dbeta + q.c_off : nullptr;
+        L.dbias = g->dbias + q.c_off;
+      }
+      if (!diag_skip(8)) TBN_TRY(tbn_launch_bn_bwd_multi(bb, st));
+      continue;
     }
-    if (!diag_skip(1))
-      TBN_TRY(tbn_launch_bn_bwd_finalize(partial, tbn_bn_bwd_parts(M, c.cout), M, c.cout, scale + c.c_off,
-                                         mean + c.c_off, rstd + c.c_off, coef, bn_grad ? g->dgamma + c.c_off : nullptr,
-                                         bn_grad ? g->dbeta + c.c_off : nullptr, g->dbias + c.c_off, st));
-    if (c.fuse_pool >= 0) {
-      const Pool& q = P->pools[c.fuse_pool];
-      const Buf& ob = P->bufs[q.outbuf];
-      if (!diag_skip(16))
-        TBN_TRY(tbn_launch_bn_bwd_apply_pooled(dptr(q.outbuf) + q.out_choff, ob.C,
-                                               (const uint8_t*)workspace + q.argmax_off, R, c.outH, c.outW, ob.H, ob.W,
-                                               q.stride, q.pad, y, c.cout, scale + c.c_off, shift + c.c_off, coef, y,
-                                               st));
-    } else if (!diag_skip(16)) {
-      TBN_TRY(tbn_launch_bn_bwd_apply(dz, c.nparts, y, M, c.cout, scale + c.c_off, shift + c.c_off, coef, y, st));
-    }
-    }
-    if (c.post_pool && !diag_skip(4))   // the 3x3 average is self-adjoint: d(conv output) = avg_pool(d(pooled))
-      TBN_TRY(tbn_launch_avgpool3_fwd(y, c.cout, dconv, c.cout, R, c.outH, c.outW, c.cout, 0, st));
-    // weight gradient -- on the aux stream when given: it only reads dy (final after bn_bwd_apply) and
+    const Conv& c = P->convs[o.idx];
+    // weight gradient -- on the aux stream when given: it only reads dy (final after the BN backward) and
     // the layer input, so it overlaps the data-gradient / BN-backward chain that continues on `st`
-    tbn_prof_label(("wgrad " + c.names[c.nparts - 1]).c_str());
+    tbn_prof_label(("wgrad " + c.parts[c.nparts - 1].name).c_str());
     hipStream_t wst = st;
     if (aux != nullptr) {
       hipEvent_t e = PM->ev[ev_next];
-      ev_next = (ev_next + 1) & 7;
+      ev_next = (ev_next + 1) % 7;
       (void)hipEventRecord(e, st);
       (void)hipStreamWaitEvent(aux, e, 0);
+      join.forked = true;
       wst = aux;
     }
     {
@@ -1060,45 +1215,14 @@ int tbn_backbone_backward(const tbn_backbone_plan* P, const float* dfeatures, co
         TBN_TRY(tbn_launch_wgrad(wp, 0, g->dweight + c.w_off, ws + P->wsplit_off, wst));
       }
     }
-    // data gradient: conv of dy with flipped / transposed weights (zero-insertion for stride 2)
     if (c.need_dgrad) {
-      tbn_prof_label(("dgrad " + c.names[c.nparts - 1]).c_str());
-      const float* wt = ws + P->wt_off + c.w_off;
+      tbn_prof_label(("dgrad " + c.parts[c.nparts - 1].name).c_str());
       ConvP p;
-      memset(&p, 0, sizeof(p));
-      p.in = dconv;
-      p.in_ld = c.cout;
-      p.wt = wt;
-      p.N = R;
-      p.H = c.outH;
-      p.W = c.outW;
-      p.OH = c.inH;
-      p.OW = c.inW;
-      p.Cin = c.cout;
-      p.Cout = c.cin;
-      p.R = p.S = c.k;
-      p.stride = 1;
-      p.pad = c.k - 1 - c.pad;
-      p.up = c.stride;
-      p.M = R * c.inH * c.inW;
-      p.K = c.k * c.k * c.cout;
-      p.alg_flops = 2.0 * M * (double)c.cout * c.k * c.k * c.cin;  // = forward count (zero-insertion not counted)
-      p.mode = CONV_EPI_PLAIN;
-      p.flags = c.dgrad_accum ? CONV_FLAG_ACCUM : 0;
-      p.nseg = 1;
-      p.seg[0].ptr = ws + ib.doff;
-      p.seg[0].ld = ib.C;
-      p.seg[0].col_begin = 0;
-      p.stages = c.d_stages;
+      fill_dgrad(P, c, ws, R, &p);
       TBN_TRY(tbn_launch_conv(p, 0, c.d_mt, c.d_nt, st));
     }
   }
-  if (aux != nullptr) {  // join: everything the caller enqueues on `st` next sees the weight gradients
-    hipEvent_t e = PM->ev[ev_next];
-    (void)hipEventRecord(e, aux);
-    (void)hipStreamWaitEvent(st, e, 0);
-  }
-  return TBN_OK;
+  return TBN_OK;   // `join` joins the aux stream: everything the caller enqueues on `st` next sees the weight gradients
 }
 
 }  // extern "C"

@@ -5,6 +5,20 @@
 enum { CONV_EPI_PLAIN = 0, CONV_EPI_STATS = 1, CONV_EPI_EVAL = 2 };
 enum { CONV_FLAG_ACCUM = 1, CONV_FLAG_RELU = 2 };
 
+// BN-backward reduce fused into a data-gradient epilogue (the launch that writes the FINAL value of dz): for the output
+// columns [col_begin, col_begin + C) -- one BN layer of the producer side -- the epilogue forms
+//   g = dz * [y*scale+shift > 0],  S1 = sum g,  S2 = sum g * (y-mean)*rstd
+// per M tile and writes them as partial[(tile*2 + {0,1}) * C + (col - col_begin)] (what bn_bwd_reduce would have
+// produced from a second pass over dz and y).  y == nullptr: columns without a BN (pass-through pool slice).
+#define TBN_CONV_MAXSEG 4
+struct RedSeg {
+  const float* y;         // BN input of that layer at column col_begin (pitch y_ld), same pixel order as the output
+  float* partial;
+  const float* stats;     // mean at stats[c], rstd at stats[chan + c], scale at stats[2*chan + c], shift at stats[3*chan + c]
+  int y_ld, col_begin, C, c_off;
+  unsigned y_bytes;
+};
+
 struct ConvP {
   const float* in;
   const float* wt;
@@ -12,9 +26,15 @@ struct ConvP {
   const float* scale;     // EVAL epilogue
   const float* shift;     // EVAL epilogue
   float* stat_partial;    // STATS epilogue: [tiles_m][2][Cout]
-  Seg seg[3];
+  Seg seg[TBN_CONV_MAXSEG];
   int nseg;
+  int raw_seg1;           // EVAL epilogue: 1 + index of a segment written as the bare accumulator (no BN fold / ReLU); 0 = none
   int in_ld;
+  // fused BN-backward reduce (PLAIN epilogue of a data gradient), see RedSeg
+  RedSeg red[TBN_CONV_MAXSEG];
+  int nred;               // 0 = off
+  int red_chan;           // stride between the mean / rstd / scale / shift arrays
+  int red_row0;           // first partial row of this launch (parity phases of one layer share a partial buffer)
   // ---- caller-facing geometry (host side fills the derived fields below from these)
   int N, H, W;            // input spatial dims (for dgrad: dims of dy)
   int OH, OW;             // full output dims
@@ -29,7 +49,7 @@ struct ConvP {
   int stages;             // host only: LDS stages (1 = two barriers per K-step, 2 = double buffered); 0 = default
   // ---- derived by tbn_launch_conv
   unsigned in_bytes, wt_bytes;          // buffer extents: out-of-range lanes read zeros (hardware check)
-  unsigned seg_bytes[3];                // extent of each output segment from seg[i].ptr
+  unsigned seg_bytes[TBN_CONV_MAXSEG];  // extent of each output segment from seg[i].ptr
   int OHs, OWs;                         // output sub-grid this launch covers (m -> n, a, b)
   int out_sy, out_oy, out_sx, out_ox;   // full-grid output pixel = (a*out_sy+out_oy, b*out_sx+out_ox)
   int in_sy, in_sx;                     // input step per sub-grid step
@@ -70,6 +90,7 @@ void tbn_prof_label(const char* label);
 // conv_igemm.hip
 void tbn_conv_pick_tile(int M, int Cout, int K, int* mt, int* nt);
 int tbn_launch_conv(ConvP p, int rowmode, int mt, int nt, hipStream_t st);
+int tbn_conv_red_rows(int N, int OH, int OW, int up, int mt);
 void tbn_wgrad_plan(int M, int Cout, int Cin, int taps, int* mt, int* nt, int* splits, int* rows_per_split);
 size_t tbn_wgrad_workspace_floats(int M, int Cout, int Cin, int taps);
 int tbn_launch_wgrad(WgradP p, int rowmode, float* dw, float* workspace, hipStream_t st);
@@ -102,12 +123,13 @@ int tbn_launch_bn_bwd_apply_pooled(const float* dpooled, int dpooled_ld, const u
                                    int OH, int OW, int stride, int pad, const float* y, int C, const float* scale,
                                    const float* shift, const float* coef, float* dy, hipStream_t st);
 // batched training-BN launches over up to three independent layers (bn_multi.hip)
-#define TBN_BN_MAXL 3
+#define TBN_BN_MAXL 4
 struct BnFwdLayer {
-  const float* y;           // BN input (P, C) pitch C
+  const float* y;           // BN input (P, C) with pitch y_ld (a column range of a wider conv output)
+  int y_ld;
   int P, C;
-  const float* partial;     // [nparts][2][C] statistics partials
-  int nparts;
+  const float* partial;     // statistics partials: partial[(i*2 + {0,1}) * pld + c], i < nparts
+  int pld, nparts;
   const float *gamma, *beta, *conv_bias;
   float *running_mean, *running_var, *save_mean, *save_rstd, *scale, *shift;
   Seg seg[3];               // destination column ranges of z
@@ -122,11 +144,13 @@ struct BnFwdBatch {
 struct BnBwdLayer {
   CSeg dz[3];               // gradient wrt z, by column range
   int nseg;
-  const float* y;           // BN input; dy is written in place
+  const float* y;           // BN input (pitch y_ld); dy is written in place
   float* dy;
+  int y_ld;
   int P, C;
   const float *scale, *shift, *mean, *rstd;
-  float* partial;           // scratch [nparts][2][C]
+  float* partial;           // [nparts][2][C]: scratch of the reduce kernel, or -- ext_parts > 0 -- already filled by the
+  int ext_parts;            //   data-gradient epilogue that finished dz (conv RedSeg): no reduce pass for this layer
   float* coef;              // scratch [3][C]
   float *dgamma, *dbeta, *dbias;
   int pch, nparts;          // filled by the launcher

@@ -211,7 +211,7 @@ def main():
         with torch.no_grad():
             out = model(inp)
             loss, _ = model.get_loss(criterion, tgt, out, 0)
-        return loss["total"]
+        return loss["total"].detach()      # no reference to the autograd graph survives the step
 
     host_inp, copy_stream, staged = None, None, [None]
     if args.host_inputs:
@@ -243,7 +243,7 @@ def main():
         loss, _ = model.get_loss(criterion, tgt, out, 0)
         loss["total"].backward()              # N>1: gradient all-reduce is issued inside backward, waited at its end
         opt.step(clip_grad=cfg.train.clip_grad)   # clip_grad_norm_(20) + SGD(momentum) in three HIP launches
-        return loss["total"]
+        return loss["total"].detach()      # no reference to the autograd graph survives the step
 
     multi = not args.no_multi_stream
     core.multi_stream = multi

@@ -17,7 +17,8 @@ Outputs (all small .npz, inputs stored as fp16-exact fp32):
   model_*.npz        reference build_model/TBNModel forward (+loss, +grads) per case
   keys_*.json        state_dict key/shape lists (checkpoint-compat contract)
   sampler.json       reference Video_Dataset index sampling on annotation rows
-Usage:  python tests/golden/make_golden.py
+  model_train_audio_dropout.npz / model_crop_repeat_eval.npz   row a11: audio-dropout branches, crop repeat
+Usage:  python tests/golden/make_golden.py [trunk] [factory] [models] [a11] [sampler]   (no argument: everything)
 """
 import importlib.util
 import json
@@ -253,6 +254,96 @@ def model_cases():
 
 
 # ---------------------------------------------------------------------------------------------
+# Row a11 of SURVEY section 8: the two host-side rules of reference core/models/model.py
+#   :215-222  audio dropout (inverted test on a host np.random.uniform() draw; the backbone still runs)
+#   :243-248  crop repeat (visual rows = k x audio rows -> audio feature tiled k times, n *= k)
+A11_DROPOUT = (["model.attention.enable=False", "data.audio.audio_length=1.279", "model.fusion_dropout=0",
+                "data.audio.dropout=0.5"], 2, 3, 64, 64)
+A11_REPEAT = (["data.flow.enable=False", "model.attention.enable=False", "data.audio.audio_length=1.279"],
+              2, 3, 64, 64, 2)
+A11_GRAD_KEYS = ["Base_RGB.conv1_7x7_s2.weight", "Base_Audio.conv1_7x7_s2.weight", "Base_Flow.inception_4a_3x3.weight",
+                 "fusion.fusion_layer.0.bias", "classifier.verb.weight"]
+
+
+def a11_cases():
+    import core.models as rm
+    import core.models.bn_inception as rbi
+    from attention_based_tbn_amd.config import get_modality
+    pre = pretrained_pair(7)
+    rbi.torch.load = lambda f, map_location=None: {k: v.clone() for k, v in
+                                                   pre["kinetics" if "kinetics" in f else "imagenet"].items()}
+    # ---- audio dropout: one NumPy seed per branch of the inverted test (draw > dropout -> feature zeroed)
+    ov, B, n, hv, ha = A11_DROPOUT
+    cfg = load_config(ov)
+    modality = get_modality(cfg)
+    seeds = {}
+    for s in range(100):
+        u = np.random.RandomState(s).uniform()
+        seeds.setdefault("drop" if u > cfg.data.audio.dropout else "keep", s)
+        if len(seeds) == 2:
+            break
+    torch.manual_seed(300)
+    model, crit, _ = rm.build_model(cfg, modality, torch.device("cpu"))
+    sd = fill_state_dict(model.state_dict(), 3000)
+    model.load_state_dict(sd)
+    with open(os.path.join(HERE, "keys_train_audio_dropout.json"), "w") as f:
+        json.dump({"overrides": ov, "modality": modality, "keys": [[k, list(v.shape)] for k, v in sd.items()],
+                   "trainable": [k for k, p in model.named_parameters() if p.requires_grad], "fill_seed": 3000,
+                   "np_seeds": seeds}, f)
+    inp, target, T, W = make_inputs(cfg, modality, B, n, hv, ha, 3100)
+    arrs = {"in_" + k: v.half() for k, v in inp.items()}
+    arrs.update({"tgt_" + k: v for k, v in target["class"].items()})
+    model.train()
+    for branch, s in seeds.items():
+        model.load_state_dict(sd)
+        model.zero_grad()
+        np.random.seed(s)
+        out = model({k: v.clone() for k, v in inp.items()})
+        loss, bs = model.get_loss(crit, target, out, epoch=0)
+        loss["total"].backward()
+        for k, v in out.items():
+            arrs[f"{branch}_out_" + k] = v
+        for k, v in loss.items():
+            arrs[f"{branch}_loss_{k}"] = torch.as_tensor(v).float()
+        params = dict(model.named_parameters())
+        for k in A11_GRAD_KEYS:
+            arrs[f"{branch}_hasgrad_" + k] = np.bool_(params[k].grad is not None)
+            if params[k].grad is not None:
+                arrs[f"{branch}_grad_" + k] = params[k].grad
+        # the audio backbone runs in both branches: its BN running statistics advance either way
+        arrs[f"{branch}_post_Base_Audio.conv1_7x7_s2_bn.running_mean"] = model.state_dict()[
+            "Base_Audio.conv1_7x7_s2_bn.running_mean"]
+    save("model_train_audio_dropout.npz", **arrs)
+
+    # ---- crop repeat: RGB carries k x the audio rows (the reference's 10-crop testing), eval mode
+    ov, B, n, hv, ha, k = A11_REPEAT
+    cfg = load_config(ov)
+    modality = get_modality(cfg)
+    torch.manual_seed(301)
+    model, crit, _ = rm.build_model(cfg, modality, torch.device("cpu"))
+    sd = fill_state_dict(model.state_dict(), 3001)
+    model.load_state_dict(sd)
+    with open(os.path.join(HERE, "keys_crop_repeat_eval.json"), "w") as f:
+        json.dump({"overrides": ov, "modality": modality, "keys": [[kk, list(v.shape)] for kk, v in sd.items()],
+                   "trainable": [kk for kk, p in model.named_parameters() if p.requires_grad], "fill_seed": 3001,
+                   "repeat": k}, f)
+    inp, target, T, W = make_inputs(cfg, modality, B, n, hv, ha, 3101)
+    g = torch.Generator().manual_seed(3102)
+    inp["RGB"] = h16(torch.rand(B, n * k, 3, hv, hv, generator=g) - 0.45)      # k crops per segment
+    arrs = {"in_" + kk: v.half() for kk, v in inp.items()}
+    arrs.update({"tgt_" + kk: v for kk, v in target["class"].items()})
+    model.eval()
+    with torch.no_grad():
+        out = model({kk: v.clone() for kk, v in inp.items()})
+    for kk, v in out.items():
+        arrs["out_" + kk] = v
+    loss, bs = model.get_loss(crit, target, out, epoch=0)
+    for kk, v in loss.items():
+        arrs[f"loss_ep0_{kk}"] = torch.as_tensor(v).float()
+    save("model_crop_repeat_eval.npz", **arrs)
+
+
+# ---------------------------------------------------------------------------------------------
 def sampler_cases():
     import pandas as pd
     import core.dataset.dataset as rds
@@ -298,7 +389,8 @@ def sampler_cases():
 if __name__ == "__main__":
     install_stubs()
     torch.set_num_threads(8)
-    trunk_pin()
-    factory_audio()
-    model_cases()
-    sampler_cases()
+    only = sys.argv[1:]          # e.g. `make_golden.py a11` regenerates just that group
+    for name, fn in (("trunk", trunk_pin), ("factory", factory_audio), ("models", model_cases), ("a11", a11_cases),
+                     ("sampler", sampler_cases)):
+        if not only or name in only:
+            fn()

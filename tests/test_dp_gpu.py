@@ -50,7 +50,7 @@ for k, gl in local.items():
     want = (parts[0] + parts[1]) / 2
     err = float((synced[k] - want).abs().max() / (want.abs().max() + 1e-20))
     assert err < 1e-5, (k, err)
-assert len(local) >= 12 and model._ready == [] and model._pending == []
+assert len(local) >= 12 and model._fired == set() and model._pending == []
 print("DP_GPU_OK", rank, len(local))
 '''
 

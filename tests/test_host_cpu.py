@@ -30,7 +30,8 @@ def test_library_loads_and_exports_every_header_symbol():
 
 
 def test_engine_layer_table_matches_reference_graph():
-    """69 convs, names/shapes as the reference graph; fused 1x1 groups adjacent in the flat arrays"""
+    """69 convs, names/shapes as the reference graph; fused 1x1 groups (1x1 | 3x3_reduce | double_3x3_reduce |
+    pool_proj of an average-pool block) adjacent in the flat arrays"""
     from attention_based_tbn_amd.core.models.bn_inception import BNInception, reference_conv_order
     net = BNInception(1000, 3)
     assert len(net._layers) == 69 and list(reference_conv_order()) == net._order
@@ -41,6 +42,10 @@ def test_engine_layer_table_matches_reference_graph():
     a, b, c = L["inception_4a_1x1"], L["inception_4a_3x3_reduce"], L["inception_4a_double_3x3_reduce"]
     assert b["c_off"] == a["c_off"] + a["cout"] and c["c_off"] == b["c_off"] + b["cout"]
     assert b["w_off"] == a["w_off"] + a["cout"] * a["cin"]
+    d = L["inception_4a_pool_proj"]        # rides in the same GEMM: the 3x3 average pool commutes with the 1x1 conv
+    assert d["c_off"] == c["c_off"] + c["cout"] and d["w_off"] == c["w_off"] + c["cout"] * c["cin"]
+    e, f = L["inception_5b_double_3x3_reduce"], L["inception_5b_pool_proj"]   # max-pool block: pool stays in front
+    assert f["c_off"] != e["c_off"] + e["cout"]
     n_params = sum(p.numel() for n, p in net.named_parameters() if not n.startswith("last_linear"))
     assert n_params == 10_272_064 + 0 or n_params > 10_000_000  # ~10.27 M
     macs = sum(v["cout"] * v["cin"] * v["k"] ** 2 for v in L.values())
@@ -146,34 +151,54 @@ sys.path.insert(0, sys.argv[1])
 from attention_based_tbn_amd.core.models.dataparallel import DataParallel
 dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
 rank = dist.get_rank()
+case = os.environ["DP_CASE"]                        # avg | drop1 (rank 1 drops the optional branch) | dropall
 torch.manual_seed(100 + rank)                       # different init per rank -> broadcast must fix it
 class Toy(nn.Module):
     def __init__(self):
         super().__init__()
         self.a = nn.Linear(8, 4); self.b = nn.Linear(4, 2)
+        self.c = nn.Linear(8, 4)                    # the "audio" branch: may be dropped per replica
         self.register_buffer("stat", torch.full((3,), float(rank)))
-    def forward(self, x): return self.b(torch.relu(self.a(x)))
+        self.register_buffer("count", torch.full((2,), rank, dtype=torch.long))
+        self.drop = False
+    def maybe_unused_parameter_prefixes(self): return ["c."] if case != "avg" else []
+    def forward(self, x):
+        u = torch.zeros(x.shape[0], 4) if self.drop else self.c(x)
+        return self.b(torch.relu(self.a(x)) + u)
     def get_loss(self, criterion, target, preds, epoch=0): return {"total": criterion(preds, target)}, preds.shape[0]
-DataParallel.SMALL = 16                             # a.weight (32 elements) takes the "large tensor" route
+DataParallel.SMALL = 16                             # a.weight / c.weight (32 elements) take the "large tensor" route
 model = DataParallel(Toy(), overlap=os.environ["DP_OVERLAP"] == "1")
 ref = Toy(); ref.load_state_dict(model.module.state_dict())
-assert float(model.module.stat[0]) == 0.0          # buffers came from rank 0
+assert float(model.module.stat[0]) == 0.0 and int(model.module.count[1]) == 0   # buffers came from rank 0 (both dtypes)
 g = torch.Generator().manual_seed(7)
 X = torch.randn(8, 8, generator=g); Y = torch.randn(8, 2, generator=g)
 xs, ys = X[rank * 4:(rank + 1) * 4], Y[rank * 4:(rank + 1) * 4]   # clips sharded by rank, no data-path collective
+drops = {"avg": (False, False), "drop1": (False, True), "dropall": (True, True)}[case]
+model.module.drop = drops[rank]
 loss, bs = model.get_loss(nn.MSELoss(), ys, model(xs), epoch=3)
 loss["total"].backward()
-nn.MSELoss()(ref(X), Y).backward()                  # full-batch reference on every rank
+outs = []
+for r in range(2):                                  # full-batch reference on every rank, same per-shard decisions
+    ref.drop = drops[r]
+    outs.append(ref(X[r * 4:(r + 1) * 4]))
+nn.MSELoss()(torch.cat(outs), Y).backward()
 for (n, p), (_, q) in zip(model.module.named_parameters(), ref.named_parameters()):
-    assert torch.allclose(p.grad, q.grad, atol=1e-6), n
-assert model._pending == [] and model._ready == [] and bs == 4
+    if q.grad is None:                              # nobody produced it: the optimiser must see None
+        assert case == "dropall" and n.startswith("c.") and p.grad is None, n
+    else:
+        assert p.grad is not None and torch.allclose(p.grad, q.grad, atol=1e-6), n
+assert model._pending == [] and model._fired == set() and bs == 4
 sd = model.state_dict(); assert all(k.startswith("module.") for k in sd)
 print("DP_OK", rank)
 '''
 
 
-@pytest.mark.parametrize("overlap", [True, False])
-def test_dataparallel_gradient_average_gloo_world2(tmp_path, overlap):
+@pytest.mark.parametrize("overlap,case", [(True, "avg"), (False, "avg"), (True, "drop1"), (False, "drop1"),
+                                          (True, "dropall")])
+def test_dataparallel_gradient_average_gloo_world2(tmp_path, overlap, case):
+    """2 gloo ranks: gradients equal the full-batch ones; with an optional branch (the audio-dropout rule, reference
+    model.py:215-222, drawn per replica) dropped on ONE rank the collective schedule still matches and the result is
+    the full-batch gradient; dropped on every rank its gradients come back as None"""
     script = tmp_path / "dp_worker.py"
     script.write_text(_DP_WORKER)
     with socket.socket() as s:
@@ -182,7 +207,7 @@ def test_dataparallel_gradient_average_gloo_world2(tmp_path, overlap):
     procs = []
     for r in range(2):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   OMP_NUM_THREADS="1", DP_OVERLAP=str(int(overlap)))
+                   OMP_NUM_THREADS="1", DP_OVERLAP=str(int(overlap)), DP_CASE=case)
         procs.append(subprocess.Popen([sys.executable, str(script), ROOT], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.STDOUT, text=True))
     outs = [p.communicate(timeout=240)[0] for p in procs]

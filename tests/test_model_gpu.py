@@ -105,6 +105,85 @@ def test_train_step_matches_reference_golden(name):
             assert rel_err(st[k[5:]].double().cpu(), data[k]) < 1e-3, k
 
 
+def test_audio_dropout_branches_match_reference_golden():
+    """row a11 (reference model.py:215-222): both branches of the host-side audio-dropout draw, training mode.
+    Dropped: zero audio feature, no gradient reaches the audio backbone, its BN running statistics still advance."""
+    cfg, modality, meta, data, inp, target = load_case("train_audio_dropout")
+    model, crit = build_product(cfg, modality, meta)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    tgt = {"class": to_dev(target["class"])}
+    model.train()
+    for branch, seed in meta["np_seeds"].items():
+        model.load_state_dict(sd)
+        model.zero_grad()
+        np.random.seed(seed)
+        out = model(to_dev(inp))
+        loss, _ = model.get_loss(crit, tgt, out, epoch=0)
+        loss["total"].backward()
+        for k, v in out.items():
+            assert rel_err(v.detach().cpu(), data[f"{branch}_out_{k}"]) < 1e-3, (branch, k)
+        for k, v in loss.items():
+            want = float(data[f"{branch}_loss_{k}"])
+            assert abs(float(torch.as_tensor(v).detach()) - want) < 1e-3 * max(1.0, abs(want)), (branch, k)
+        grads = reference_named_grads(model)
+        for k in data:
+            if not k.startswith(f"{branch}_hasgrad_"):
+                continue
+            name_ = k[len(f"{branch}_hasgrad_"):]
+            assert (name_ in grads) == bool(data[k]), (branch, name_)
+            if bool(data[k]):
+                want = torch.from_numpy(data[f"{branch}_grad_{name_}"])
+                assert l2_err(grads[name_], want) < 2e-2 and cosine(grads[name_].cpu(), want) > 0.999, (branch, name_)
+        key = "Base_Audio.conv1_7x7_s2_bn.running_mean"
+        assert rel_err(model.state_dict()[key].cpu(), data[f"{branch}_post_{key}"]) < 1e-3, branch
+        assert (model.Base_Audio.flat_weight.grad is None) == (branch == "drop")
+
+
+def test_crop_repeat_eval_matches_reference_golden():
+    """row a11 (reference model.py:243-248): RGB rows = 2 x audio rows (multi-crop testing) -> tiled audio feature"""
+    cfg, modality, meta, data, inp, target = load_case("crop_repeat_eval")
+    model, crit = build_product(cfg, modality, meta)
+    model.eval()
+    with torch.no_grad():
+        out = model(to_dev(inp))
+    for k, v in out.items():
+        assert tuple(v.shape) == data["out_" + k].shape, k
+        assert rel_err(v.cpu(), data["out_" + k]) < 1e-3, (k, rel_err(v.cpu(), data["out_" + k]))
+    loss, bs = model.get_loss(crit, {"class": to_dev(target["class"])}, out, epoch=0)
+    for k, v in loss.items():
+        want = float(data[f"loss_ep0_{k}"])
+        assert abs(float(torch.as_tensor(v).detach()) - want) < 1e-3 * max(1.0, abs(want)), k
+
+
+def test_product_bninception_factory_matches_reference():
+    """row a2 (reference bn_inception.py:38-107) on the PRODUCT factory: Audio conv1 = channel mean of the RGB filter,
+    key reconciliation, the kinetics 10-channel conv1, `last_linear` removal -- against the reference-written fixture"""
+    import os
+    from oracle.fill import pretrained_pair
+    from tests.util import GOLDEN
+    from attention_based_tbn_amd.core.models import bninception
+    d = np.load(os.path.join(GOLDEN, "factory_audio.npz"))
+    pre = pretrained_pair(int(d["seed"]))
+    m = bninception(1, "Audio", pretrained="imagenet", is_audio=True, attend=True, state_dict=pre["imagenet"]).to(DEV)
+    assert not hasattr(m, "last_linear") and not bool(d["has_last_linear"])
+    assert m.is_audio and m.attend and m.feature_size == 1024
+    assert torch.equal(m.state_dict()["conv1_7x7_s2.weight"].cpu(), torch.from_numpy(d["conv1_w"]))
+    m.eval()
+    with torch.no_grad():
+        y = m(torch.from_numpy(d["x"].astype(np.float32)).to(DEV))
+    assert tuple(y.shape) == d["y"].shape == (1, 1024, 1, 8)
+    assert rel_err(y.cpu(), d["y"]) < 1e-3
+    mf = bninception(10, "Flow", pretrained="kinetics", state_dict=pre["kinetics"])
+    w = mf.state_dict()["conv1_7x7_s2.weight"]
+    assert tuple(w.shape) == (64, 10, 7, 7)
+    assert abs(float(w.double().sum()) - float(d["flow_conv1_w_sum"])) < 1e-9
+    mr = bninception(3, "RGB", pretrained="imagenet", state_dict=pre["imagenet"])
+    assert torch.equal(mr.state_dict()["conv1_7x7_s2.weight"], pre["imagenet"]["conv1_7x7_s2.weight"])
+    assert not hasattr(mr, "last_linear") and not hasattr(mf, "last_linear")
+    with pytest.raises(RuntimeError):       # strict load (reference :101): a 3-channel filter does not fit the flow stem
+        bninception(10, "Flow", pretrained="kinetics", state_dict=pre["imagenet"])
+
+
 def l2_err(a, b):
     """relative L2 error: robust to the single-element ReLU / max-pool decision flips of fp32"""
     a, b = torch.as_tensor(a).double().flatten().cpu(), torch.as_tensor(b).double().flatten().cpu()

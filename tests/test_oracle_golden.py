@@ -105,6 +105,53 @@ def test_train_forward_loss_grads(name):
             assert rel_err(st[k[5:]].double(), data[k]) < TOL, k
 
 
+def test_audio_dropout_branches():
+    """row a11, reference model.py:215-222: training, M > 1, data.audio.dropout = 0.5 -- the audio feature is zeroed when
+    the host draw np.random.uniform() EXCEEDS the dropout value (inverted test), the audio backbone runs either way"""
+    cfg, modality, meta, data, inp, target = load_case("train_audio_dropout")
+    model, crit = build_oracle(cfg, modality, meta)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    model.train()
+    assert set(meta["np_seeds"]) == {"drop", "keep"}
+    for branch, seed in meta["np_seeds"].items():
+        model.load_state_dict(sd)
+        model.zero_grad()
+        np.random.seed(seed)
+        out = model({k: v.clone() for k, v in inp.items()})
+        loss, _ = model.get_loss(crit, target, out, epoch=0)
+        loss["total"].backward()
+        for k, v in out.items():
+            assert rel_err(v, data[f"{branch}_out_{k}"]) < TOL, (branch, k)
+        for k, v in loss.items():
+            v = float(torch.as_tensor(v).detach())
+            assert abs(v - float(data[f"{branch}_loss_{k}"])) < 1e-5 * max(1, abs(v)), (branch, k)
+        params = dict(model.named_parameters())
+        for k in data:
+            if k.startswith(f"{branch}_hasgrad_"):
+                name = k[len(f"{branch}_hasgrad_"):]
+                assert (params[name].grad is not None) == bool(data[k]), (branch, name)
+                if bool(data[k]):
+                    assert rel_err(params[name].grad, data[f"{branch}_grad_{name}"]) < 2e-4, (branch, name)
+        key = "Base_Audio.conv1_7x7_s2_bn.running_mean"
+        assert rel_err(model.state_dict()[key], data[f"{branch}_post_{key}"]) < TOL
+    assert not bool(data["drop_hasgrad_Base_Audio.conv1_7x7_s2.weight"])    # dropped branch: no audio gradient
+
+
+def test_crop_repeat_eval():
+    """row a11, reference model.py:243-248: RGB carries k x the audio rows -> audio feature tiled k times, n *= k"""
+    cfg, modality, meta, data, inp, target = load_case("crop_repeat_eval")
+    model, crit = build_oracle(cfg, modality, meta)
+    assert inp["RGB"].shape[1] == meta["repeat"] * inp["Audio"].shape[1]
+    model.eval()
+    with torch.no_grad():
+        out = model({k: v.clone() for k, v in inp.items()})
+    for k, v in out.items():
+        assert v.shape == data["out_" + k].shape and rel_err(v, data["out_" + k]) < TOL, k
+    loss, bs = model.get_loss(crit, target, out, epoch=0)
+    for k, v in loss.items():
+        assert abs(float(v) - float(data[f"loss_ep0_{k}"])) < 1e-5 * max(1, abs(float(v))), k
+
+
 def test_sampler_bit_exact():
     """oracle sampler vs reference Video_Dataset.__getitem__ index selection (dataset.py:155-239)"""
     from oracle.sampler import sample_indices
