@@ -11,6 +11,7 @@
 // written as per-workgroup partials and summed in fp64 by a finalize kernel (deterministic).
 #include "tbn_common.h"
 #include "tbn_kernels.h"
+#include "tbn_bn_dev.h"
 
 static inline int pick_chunk(int P, int rp) {
   int pch = cdiv(P, 512);
@@ -70,25 +71,13 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
                                                           float* running_var, float momentum, float eps,
                                                           float* save_mean, float* save_rstd, float* scale,
                                                           float* shift) {
-  // 8 channels per workgroup, 32 slots per channel: short dependent chains, fixed summation order
-  __shared__ double red[2][32][8];
-  const int tid = threadIdx.x, cl = tid & 7, slot = tid >> 3;
-  const int c = blockIdx.x * 8 + cl;
-  double a = 0.0, b = 0.0;
-  if (c < C)
-    for (int i = slot; i < nparts; i += 32) {
-      a += (double)partial[((size_t)i * 2 + 0) * C + c];
-      b += (double)partial[((size_t)i * 2 + 1) * C + c];
-    }
-  red[0][slot][cl] = a;
-  red[1][slot][cl] = b;
-  __syncthreads();
-  if (slot == 0 && c < C) {
-    double s1 = 0.0, s2 = 0.0;
-    for (int k = 0; k < 32; ++k) {
-      s1 += red[0][k][cl];
-      s2 += red[1][k][cl];
-    }
+  // 16 channels per workgroup, fixed summation order (tbn_bn_dev.h)
+  __shared__ double red[64 * 32];
+  const int tid = threadIdx.x;
+  const int c = blockIdx.x * 16 + tid;
+  double s1, s2;
+  tbn_sum_partials16(partial, C, nparts, blockIdx.x * 16, C, red, &s1, &s2);
+  if (tid < 16 && c < C) {
     const double mean = s1 / P;
     double var = s2 / P - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -111,7 +100,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
 int tbn_launch_bn_finalize(const float* partial, int nparts, int P, int C, const float* gamma, const float* beta,
                            const float* conv_bias, float* running_mean, float* running_var, float momentum, float eps,
                            float* save_mean, float* save_rstd, float* scale, float* shift, hipStream_t st) {
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 8)), dim3(256), 0, st, partial, nparts, P, C, gamma, beta,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, st, partial, nparts, P, C, gamma, beta,
                      conv_bias, running_mean, running_var, momentum, eps, save_mean, save_rstd, scale, shift);
   TBN_CHECK_LAUNCH("bn_finalize");
   return TBN_OK;
@@ -435,24 +424,12 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
                                                               const float* __restrict__ mean,
                                                               const float* __restrict__ rstd, float* coef,
                                                               float* dgamma, float* dbeta, float* dbias) {
-  __shared__ double red[2][32][8];
-  const int tid = threadIdx.x, cl = tid & 7, slot = tid >> 3;
-  const int c = blockIdx.x * 8 + cl;
-  double a = 0.0, b = 0.0;
-  if (c < C)
-    for (int i = slot; i < nparts; i += 32) {
-      a += (double)partial[((size_t)i * 2 + 0) * C + c];
-      b += (double)partial[((size_t)i * 2 + 1) * C + c];
-    }
-  red[0][slot][cl] = a;
-  red[1][slot][cl] = b;
-  __syncthreads();
-  if (slot == 0 && c < C) {
-    double s1 = 0.0, s2 = 0.0;
-    for (int k = 0; k < 32; ++k) {
-      s1 += red[0][k][cl];
-      s2 += red[1][k][cl];
-    }
+  __shared__ double red[64 * 32];
+  const int tid = threadIdx.x;
+  const int c = blockIdx.x * 16 + tid;
+  double s1, s2;
+  tbn_sum_partials16(partial, C, nparts, blockIdx.x * 16, C, red, &s1, &s2);
+  if (tid < 16 && c < C) {
     const double sc = scale[c], rs = rstd[c], mu = mean[c];
     const double bb = -sc * rs * (s2 / P);
     coef[c] = (float)sc;
@@ -468,7 +445,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
 int tbn_launch_bn_bwd_finalize(const float* partial, int nparts, int P, int C, const float* scale, const float* mean,
                                const float* rstd, float* coef, float* dgamma, float* dbeta, float* dbias,
                                hipStream_t st) {
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 8)), dim3(256), 0, st, partial, nparts, P, C, scale, mean,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, st, partial, nparts, P, C, scale, mean,
                      rstd, coef, dgamma, dbeta, dbias);
   TBN_CHECK_LAUNCH("bn_bwd_finalize");
   return TBN_OK;

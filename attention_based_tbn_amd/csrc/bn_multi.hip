@@ -9,6 +9,7 @@
 // arithmetic, same summation order: results are bit-identical to the per-layer launches).
 #include "tbn_common.h"
 #include "tbn_kernels.h"
+#include "tbn_bn_dev.h"
 
 namespace {
 
@@ -27,28 +28,16 @@ inline int ew_grid(size_t items) {
 
 // ---------------------------------------------------------------- forward: finalize
 __global__ __launch_bounds__(256) void bn_finalize_multi_kernel(BnFwdBatch b) {
-  __shared__ double red[2][32][8];
+  __shared__ double red[64 * 32];
   const int li = find_layer(b.fin_blk0, b.n, blockIdx.x);
   const BnFwdLayer& L = b.l[li];
   const int blk = blockIdx.x - b.fin_blk0[li];
   const int C = L.C, P = L.P;
-  const int tid = threadIdx.x, cl = tid & 7, slot = tid >> 3;
-  const int c = blk * 8 + cl;
-  double a = 0.0, s = 0.0;
-  if (c < C)
-    for (int i = slot; i < L.nparts; i += 32) {
-      a += (double)L.partial[((size_t)i * 2 + 0) * L.pld + c];
-      s += (double)L.partial[((size_t)i * 2 + 1) * L.pld + c];
-    }
-  red[0][slot][cl] = a;
-  red[1][slot][cl] = s;
-  __syncthreads();
-  if (slot == 0 && c < C) {
-    double s1 = 0.0, s2 = 0.0;
-    for (int k = 0; k < 32; ++k) {
-      s1 += red[0][k][cl];
-      s2 += red[1][k][cl];
-    }
+  const int tid = threadIdx.x;
+  const int c = blk * 16 + tid;
+  double s1, s2;
+  tbn_sum_partials16(L.partial, L.pld, L.nparts, blk * 16, C, red, &s1, &s2);
+  if (tid < 16 && c < C) {
     const double mean = s1 / P;
     double var = s2 / P - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -102,7 +91,7 @@ int tbn_launch_bn_fwd_multi(BnFwdBatch& b, hipStream_t st) {
                 "bn_fwd_multi: bad C / pitch / nseg");
     for (int s = 0; s < L.nseg; ++s)
       TBN_REQUIRE(L.seg[s].ld % 4 == 0 && L.seg[s].col_begin % 4 == 0, "bn_fwd_multi: segment pitch/offset must be x4");
-    b.fin_blk0[i + 1] = b.fin_blk0[i] + cdiv(L.C, 8);
+    b.fin_blk0[i + 1] = b.fin_blk0[i] + cdiv(L.C, 16);
     b.app_blk0[i + 1] = b.app_blk0[i] + ew_grid((size_t)L.P * L.C / 4);
   }
   hipLaunchKernelGGL(bn_finalize_multi_kernel, dim3(b.fin_blk0[b.n]), dim3(256), 0, st, b);
@@ -166,28 +155,16 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_multi_kernel(BnBwdBatch b) 
 
 // coef[0][c]=a, coef[1][c]=b, coef[2][c]=cst with dy = a*g + b*y + cst
 __global__ __launch_bounds__(256) void bn_bwd_finalize_multi_kernel(BnBwdBatch b) {
-  __shared__ double red[2][32][8];
+  __shared__ double red[64 * 32];
   const int li = find_layer(b.fin_blk0, b.n, blockIdx.x);
   const BnBwdLayer& L = b.l[li];
   const int blk = blockIdx.x - b.fin_blk0[li];
   const int C = L.C, P = L.P;
-  const int tid = threadIdx.x, cl = tid & 7, slot = tid >> 3;
-  const int c = blk * 8 + cl;
-  double a = 0.0, s = 0.0;
-  if (c < C)
-    for (int i = slot; i < L.nparts; i += 32) {
-      a += (double)L.partial[((size_t)i * 2 + 0) * C + c];
-      s += (double)L.partial[((size_t)i * 2 + 1) * C + c];
-    }
-  red[0][slot][cl] = a;
-  red[1][slot][cl] = s;
-  __syncthreads();
-  if (slot == 0 && c < C) {
-    double s1 = 0.0, s2 = 0.0;
-    for (int k = 0; k < 32; ++k) {
-      s1 += red[0][k][cl];
-      s2 += red[1][k][cl];
-    }
+  const int tid = threadIdx.x;
+  const int c = blk * 16 + tid;
+  double s1, s2;
+  tbn_sum_partials16(L.partial, C, L.nparts, blk * 16, C, red, &s1, &s2);
+  if (tid < 16 && c < C) {
     const double sc = L.scale[c], rs = L.rstd[c], mu = L.mean[c];
     const double bb = -sc * rs * (s2 / P);
     L.coef[c] = (float)sc;
@@ -252,7 +229,7 @@ int tbn_launch_bn_bwd_multi(BnBwdBatch& b, hipStream_t st) {
       red_blocks = 0;
     }
     b.red_blk0[i + 1] = b.red_blk0[i] + red_blocks;
-    b.fin_blk0[i + 1] = b.fin_blk0[i] + cdiv(L.C, 8);
+    b.fin_blk0[i + 1] = b.fin_blk0[i] + cdiv(L.C, 16);
     b.app_blk0[i + 1] = b.app_blk0[i] + ew_grid((size_t)L.P * L.C / 4);
   }
   if (b.red_blk0[b.n] > 0) {

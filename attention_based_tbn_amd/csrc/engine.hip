@@ -499,7 +499,7 @@ void plan_memory(tbn_backbone_plan* P) {
       f.cout[f.n] = (short)c.cout;
       f.cin[f.n] = (short)c.cin;
       f.taps[f.n] = (short)(c.k * c.k);
-      f.blk0[f.n + 1] = f.blk0[f.n] + cdiv(c.cin, 32) * cdiv(c.cout, 32) * c.k * c.k;
+      f.blk0[f.n + 1] = f.blk0[f.n] + cdiv(c.cin, 32) * cdiv(c.cout, 32);   // one workgroup per 32 x 32 tile, all taps
       ++f.n;
     }
   P->partial_floats = partial;
