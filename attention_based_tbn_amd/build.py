@@ -12,6 +12,8 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-u
          "-I" + os.path.join(os.path.dirname(HERE), "include")]
 if os.environ.get("TBN_DIAG") == "1":         # timing-diagnostic build (engine can skip kernel groups; results invalid)
     FLAGS.append("-DTBN_DIAG=1")
+if os.environ.get("TBN_EXTRA_FLAGS"):         # experiments (same-box A/B of a -D switch): never the shipped build
+    FLAGS += os.environ["TBN_EXTRA_FLAGS"].split()
 if os.environ.get("TBN_ABLATE") == "1":      # timing-ablation build for scripts/conv_ablate.py (never the shipped one)
     FLAGS.append("-DTBN_ABLATE=1")
 

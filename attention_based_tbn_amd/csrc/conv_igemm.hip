@@ -73,6 +73,161 @@ __device__ __forceinline__ float4 buf_load4(i32x4 r, unsigned voff, unsigned sof
   return make_float4(v.x, v.y, v.z, v.w);
 }
 
+// ---------------------------------------------------------------- epilogue (shared by the GEMM bodies)
+// EPI 1 / 2 work on the bias-free accumulator (training: a per-channel constant cancels in the batch-stat
+// BN; eval: the bias is folded into `shift`).  Rows >= M and columns >= Cout hold exact zeros, so the
+// statistics need no masking.  Stores are buffer stores: the lane offset is computed once per 32x32
+// sub-tile, the per-register row step rides in the scalar offset -> no VALU address math, no branches.
+// Precondition: every wave has passed a barrier after its last LDS tile read (`lds` is reused for the partial sums).
+template <int MT, int NT, int EPI, bool RED>
+__device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[MT][NT], float* lds, const int tm,
+                                              const int m0, const int n0) {
+  constexpr int BM = 128 * MT, BN = 32 * NT;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lrow = lane & 31, lhalf = lane >> 5;
+  float* red = lds;  // [2][4 waves][BN] for the BN-statistics partials (tiles are dead now)
+  const int mrow0 = m0 + wave * 32 * MT + 4 * lhalf;  // + i*32 + 8*g + q  (accumulator register e = 4*g + q)
+  const bool tile_full = (m0 + BM <= p.M);
+  constexpr bool scatter = (EPI == 3);  // strided data-gradient phase
+  constexpr bool SUMS = (EPI == 1) || RED;   // (the K loop ends with a barrier: `red` may overlay the tiles)
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int colb = n0 + j * 32;
+    if (colb >= p.Cout) continue;  // block-uniform
+    const int col = colb + lrow;
+    const bool col_ok = col < p.Cout;
+    int sg = 0;
+    if (p.nseg > 1 && colb >= p.seg[1].col_begin) sg = 1;
+    if (p.nseg > 2 && colb >= p.seg[2].col_begin) sg = 2;
+    if (p.nseg > 3 && colb >= p.seg[3].col_begin) sg = 3;
+    const int old = p.seg[sg].ld;
+    const i32x4 o_rsrc = make_rsrc(p.seg[sg].ptr, p.seg_bytes[sg]);
+    const unsigned col_off = (unsigned)(col - p.seg[sg].col_begin) * 4u;
+    const float bias = (EPI == 0 || EPI == 3) ? ((p.bias != nullptr && col_ok) ? p.bias[col] : 0.f) : 0.f;
+    float sc = 1.f, sh = 0.f;
+    bool raw = false;
+    if (EPI == 2) {
+      raw = (p.raw_seg1 == sg + 1);   // block-uniform
+      if (col_ok && !raw) {
+        sc = p.scale[col];
+        sh = p.shift[col];
+      }
+    }
+    // fused BN-backward reduce: the producer layer of these 32 columns (block-uniform, segments start on x32 columns)
+    int rs = 0;
+    bool red_on = false;
+    i32x4 y_rsrc = o_rsrc;
+    unsigned ycol_off = 0u;
+    int yld = 0;
+    float b_sc = 0.f, b_sh = 0.f, b_mu = 0.f, b_rs = 0.f;
+    if (RED) {
+      if (p.nred > 1 && colb >= p.red[1].col_begin) rs = 1;
+      if (p.nred > 2 && colb >= p.red[2].col_begin) rs = 2;
+      if (p.nred > 3 && colb >= p.red[3].col_begin) rs = 3;
+      red_on = p.red[rs].y != nullptr && colb < p.red[rs].col_begin + p.red[rs].C;
+      if (red_on) {
+        y_rsrc = make_rsrc(p.red[rs].y, p.red[rs].y_bytes);
+        yld = p.red[rs].y_ld;
+        const int lc = col - p.red[rs].col_begin;
+        ycol_off = (unsigned)lc * 4u;
+        if (lc < p.red[rs].C) {
+          const float* stp = p.red[rs].stats + p.red[rs].c_off + lc;
+          b_mu = stp[0];
+          b_rs = stp[p.red_chan];
+          b_sc = stp[2 * p.red_chan];
+          b_sh = stp[3 * p.red_chan];
+        }
+      }
+    }
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const unsigned vbase = col_ok ? (unsigned)(mrow0 + i * 32) * (unsigned)old * 4u + col_off : TBN_OOB;
+      const unsigned ybase = (RED && red_on && col_ok) ? (unsigned)(mrow0 + i * 32) * (unsigned)yld * 4u + ycol_off : TBN_OOB;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int dm = 8 * (e >> 2) + (e & 3);
+        float v = acc[i][j][e];
+        if (EPI == 1) {
+          s1 += v;
+          s2 = fmaf(v, v, s2);
+        } else if (EPI == 2) {
+          if (!raw) v = fmaxf(fmaf(v, sc, sh), 0.f);
+        } else {
+          v += bias;
+        }
+        unsigned voff = vbase, soff = (unsigned)(dm * old) * 4u;
+        unsigned yvoff = ybase, ysoff = (unsigned)(dm * yld) * 4u;
+        if (scatter) {
+          const int m = mrow0 + i * 32 + dm;
+          const uint32_t n = fdiv((uint32_t)m, p.div_ohw);
+          const uint32_t rem = (uint32_t)m - n * p.div_ohw.d;
+          const uint32_t a = fdiv(rem, p.div_ow);
+          const uint32_t b = rem - a * p.div_ow.d;
+          const unsigned opix = (unsigned)(((int)n * p.OH + ((int)a * p.out_sy + p.out_oy)) * p.OW + ((int)b * p.out_sx + p.out_ox));
+          voff = (m < p.M && col_ok) ? opix * (unsigned)old * 4u + col_off : TBN_OOB;
+          soff = 0u;
+          if (RED) {
+            yvoff = (m < p.M && col_ok && red_on) ? opix * (unsigned)yld * 4u + ycol_off : TBN_OOB;
+            ysoff = 0u;
+          }
+        } else if (!tile_full) {
+          const int m = mrow0 + i * 32 + dm;
+          voff = (m < p.M) ? vbase : TBN_OOB;  // the scalar offset is not bounds-checked: mask the row here
+          if (RED) yvoff = (m < p.M) ? ybase : TBN_OOB;
+        }
+        if (EPI == 0 || EPI == 3) {
+          if (p.flags & CONV_FLAG_ACCUM) v += tbn_llvm_buffer_load_f32(o_rsrc, (int)voff, (int)soff, 0);
+          if (p.flags & CONV_FLAG_RELU) v = fmaxf(v, 0.f);
+        }
+        tbn_llvm_buffer_store_f32(v, o_rsrc, (int)voff, (int)soff, 0);
+        if (RED) {
+          // rows >= M / masked lanes: v may hold junk only where the store was masked too -> mask g the same way
+          const float yv = tbn_llvm_buffer_load_f32(y_rsrc, (int)yvoff, (int)ysoff, 0);
+          const float g = (yvoff != TBN_OOB && fmaf(yv, b_sc, b_sh) > 0.f) ? v : 0.f;
+          s1 += g;
+          s2 = fmaf(g, (yv - b_mu) * b_rs, s2);
+        }
+      }
+    }
+    if (SUMS) {
+      s1 += __shfl_xor(s1, 32);
+      s2 += __shfl_xor(s2, 32);
+      if (lhalf == 0) {
+        red[(0 * 4 + wave) * BN + j * 32 + lrow] = s1;
+        red[(1 * 4 + wave) * BN + j * 32 + lrow] = s2;
+      }
+    }
+  }
+  if (SUMS) {
+    __syncthreads();
+    if (tid < BN && n0 + tid < p.Cout) {
+      float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        t1 += red[(0 * 4 + w) * BN + tid];
+        t2 += red[(1 * 4 + w) * BN + tid];
+      }
+      if (EPI == 1) {
+        p.stat_partial[((size_t)tm * 2 + 0) * p.Cout + n0 + tid] = t1;
+        p.stat_partial[((size_t)tm * 2 + 1) * p.Cout + n0 + tid] = t2;
+      } else {
+        const int col = n0 + tid;
+        int rs = 0;
+        if (p.nred > 1 && col >= p.red[1].col_begin) rs = 1;
+        if (p.nred > 2 && col >= p.red[2].col_begin) rs = 2;
+        if (p.nred > 3 && col >= p.red[3].col_begin) rs = 3;
+        const int lc = col - p.red[rs].col_begin;
+        if (p.red[rs].y != nullptr && lc < p.red[rs].C) {
+          float* part = p.red[rs].partial + (size_t)(p.red_row0 + tm) * 2 * p.red[rs].C;
+          part[lc] = t1;
+          part[p.red[rs].C + lc] = t2;
+        }
+      }
+    }
+  }
+}
+
 // EPI: 0 plain (+bias, optional ReLU / accumulate), 1 training-BN statistics, 2 eval-BN fold + ReLU,
 //      3 plain with output scatter (parity phase of a strided data gradient)
 // RED (EPI 0 / 3 only): the epilogue also forms the BN-backward reduce partials of the layers that produced the
@@ -282,158 +437,175 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& p, const int bid, f
     }
   }
 
-  // ---------------------------------------------------------------- epilogue
-  // EPI 1 / 2 work on the bias-free accumulator (training: a per-channel constant cancels in the batch-stat
-  // BN; eval: the bias is folded into `shift`).  Rows >= M and columns >= Cout hold exact zeros, so the
-  // statistics need no masking.  Stores are buffer stores: the lane offset is computed once per 32x32
-  // sub-tile, the per-register row step rides in the scalar offset -> no VALU address math, no branches.
-  float* red = lds;  // [2][4 waves][BN] for the BN-statistics partials (tiles are dead now)
-  const int mrow0 = m0 + wave * 32 * MT + 4 * lhalf;  // + i*32 + 8*g + q  (accumulator register e = 4*g + q)
-  const bool tile_full = (m0 + BM <= p.M);
-  constexpr bool scatter = (EPI == 3);  // strided data-gradient phase
-  constexpr bool SUMS = (EPI == 1) || RED;   // (the K loop ends with a barrier: `red` may overlay the tiles)
-#pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    const int colb = n0 + j * 32;
-    if (colb >= p.Cout) continue;  // block-uniform
-    const int col = colb + lrow;
-    const bool col_ok = col < p.Cout;
-    int sg = 0;
-    if (p.nseg > 1 && colb >= p.seg[1].col_begin) sg = 1;
-    if (p.nseg > 2 && colb >= p.seg[2].col_begin) sg = 2;
-    if (p.nseg > 3 && colb >= p.seg[3].col_begin) sg = 3;
-    const int old = p.seg[sg].ld;
-    const i32x4 o_rsrc = make_rsrc(p.seg[sg].ptr, p.seg_bytes[sg]);
-    const unsigned col_off = (unsigned)(col - p.seg[sg].col_begin) * 4u;
-    const float bias = (EPI == 0 || EPI == 3) ? ((p.bias != nullptr && col_ok) ? p.bias[col] : 0.f) : 0.f;
-    float sc = 1.f, sh = 0.f;
-    bool raw = false;
-    if (EPI == 2) {
-      raw = (p.raw_seg1 == sg + 1);   // block-uniform
-      if (col_ok && !raw) {
-        sc = p.scale[col];
-        sh = p.shift[col];
-      }
-    }
-    // fused BN-backward reduce: the producer layer of these 32 columns (block-uniform, segments start on x32 columns)
-    int rs = 0;
-    bool red_on = false;
-    i32x4 y_rsrc = o_rsrc;
-    unsigned ycol_off = 0u;
-    int yld = 0;
-    float b_sc = 0.f, b_sh = 0.f, b_mu = 0.f, b_rs = 0.f;
-    if (RED) {
-      if (p.nred > 1 && colb >= p.red[1].col_begin) rs = 1;
-      if (p.nred > 2 && colb >= p.red[2].col_begin) rs = 2;
-      if (p.nred > 3 && colb >= p.red[3].col_begin) rs = 3;
-      red_on = p.red[rs].y != nullptr && colb < p.red[rs].col_begin + p.red[rs].C;
-      if (red_on) {
-        y_rsrc = make_rsrc(p.red[rs].y, p.red[rs].y_bytes);
-        yld = p.red[rs].y_ld;
-        const int lc = col - p.red[rs].col_begin;
-        ycol_off = (unsigned)lc * 4u;
-        if (lc < p.red[rs].C) {
-          const float* stp = p.red[rs].stats + p.red[rs].c_off + lc;
-          b_mu = stp[0];
-          b_rs = stp[p.red_chan];
-          b_sc = stp[2 * p.red_chan];
-          b_sh = stp[3 * p.red_chan];
-        }
-      }
-    }
-    float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      const unsigned vbase = col_ok ? (unsigned)(mrow0 + i * 32) * (unsigned)old * 4u + col_off : TBN_OOB;
-      const unsigned ybase = (RED && red_on && col_ok) ? (unsigned)(mrow0 + i * 32) * (unsigned)yld * 4u + ycol_off : TBN_OOB;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int dm = 8 * (e >> 2) + (e & 3);
-        float v = acc[i][j][e];
-        if (EPI == 1) {
-          s1 += v;
-          s2 = fmaf(v, v, s2);
-        } else if (EPI == 2) {
-          if (!raw) v = fmaxf(fmaf(v, sc, sh), 0.f);
-        } else {
-          v += bias;
-        }
-        unsigned voff = vbase, soff = (unsigned)(dm * old) * 4u;
-        unsigned yvoff = ybase, ysoff = (unsigned)(dm * yld) * 4u;
-        if (scatter) {
-          const int m = mrow0 + i * 32 + dm;
-          const uint32_t n = fdiv((uint32_t)m, p.div_ohw);
-          const uint32_t rem = (uint32_t)m - n * p.div_ohw.d;
-          const uint32_t a = fdiv(rem, p.div_ow);
-          const uint32_t b = rem - a * p.div_ow.d;
-          const unsigned opix = (unsigned)(((int)n * p.OH + ((int)a * p.out_sy + p.out_oy)) * p.OW + ((int)b * p.out_sx + p.out_ox));
-          voff = (m < p.M && col_ok) ? opix * (unsigned)old * 4u + col_off : TBN_OOB;
-          soff = 0u;
-          if (RED) {
-            yvoff = (m < p.M && col_ok && red_on) ? opix * (unsigned)yld * 4u + ycol_off : TBN_OOB;
-            ysoff = 0u;
-          }
-        } else if (!tile_full) {
-          const int m = mrow0 + i * 32 + dm;
-          voff = (m < p.M) ? vbase : TBN_OOB;  // the scalar offset is not bounds-checked: mask the row here
-          if (RED) yvoff = (m < p.M) ? ybase : TBN_OOB;
-        }
-        if (EPI == 0 || EPI == 3) {
-          if (p.flags & CONV_FLAG_ACCUM) v += tbn_llvm_buffer_load_f32(o_rsrc, (int)voff, (int)soff, 0);
-          if (p.flags & CONV_FLAG_RELU) v = fmaxf(v, 0.f);
-        }
-        tbn_llvm_buffer_store_f32(v, o_rsrc, (int)voff, (int)soff, 0);
-        if (RED) {
-          // rows >= M / masked lanes: v may hold junk only where the store was masked too -> mask g the same way
-          const float yv = tbn_llvm_buffer_load_f32(y_rsrc, (int)yvoff, (int)ysoff, 0);
-          const float g = (yvoff != TBN_OOB && fmaf(yv, b_sc, b_sh) > 0.f) ? v : 0.f;
-          s1 += g;
-          s2 = fmaf(g, (yv - b_mu) * b_rs, s2);
-        }
-      }
-    }
-    if (SUMS) {
-      s1 += __shfl_xor(s1, 32);
-      s2 += __shfl_xor(s2, 32);
-      if (lhalf == 0) {
-        red[(0 * 4 + wave) * BN + j * 32 + lrow] = s1;
-        red[(1 * 4 + wave) * BN + j * 32 + lrow] = s2;
-      }
-    }
-  }
-  if (SUMS) {
-    __syncthreads();
-    if (tid < BN && n0 + tid < p.Cout) {
-      float t1 = 0.f, t2 = 0.f;
-#pragma unroll
-      for (int w = 0; w < 4; ++w) {
-        t1 += red[(0 * 4 + w) * BN + tid];
-        t2 += red[(1 * 4 + w) * BN + tid];
-      }
-      if (EPI == 1) {
-        p.stat_partial[((size_t)tm * 2 + 0) * p.Cout + n0 + tid] = t1;
-        p.stat_partial[((size_t)tm * 2 + 1) * p.Cout + n0 + tid] = t2;
-      } else {
-        const int col = n0 + tid;
-        int rs = 0;
-        if (p.nred > 1 && col >= p.red[1].col_begin) rs = 1;
-        if (p.nred > 2 && col >= p.red[2].col_begin) rs = 2;
-        if (p.nred > 3 && col >= p.red[3].col_begin) rs = 3;
-        const int lc = col - p.red[rs].col_begin;
-        if (p.red[rs].y != nullptr && lc < p.red[rs].C) {
-          float* part = p.red[rs].partial + (size_t)(p.red_row0 + tm) * 2 * p.red[rs].C;
-          part[lc] = t1;
-          part[p.red[rs].C + lc] = t2;
-        }
-      }
-    }
-  }
+  conv_epilogue<MT, NT, EPI, RED>(p, acc, lds, tm, m0, n0);
 }
 
 template <int MT, int NT, bool ROWMODE, int EPI, int STAGES, bool RED = false>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
   __shared__ __attribute__((aligned(16))) float lds[STAGES * (128 * MT + 32 * NT) * LDT];
   conv_igemm_body<MT, NT, ROWMODE, EPI, STAGES, RED>(p, blockIdx.x, lds);
+}
+
+// ------------------------------------------------------------------------------------------
+// 3x3 / stride 1 / pad 1 convolution (forward of such a layer, and its data gradient, which has the same form) with
+// the INPUT PATCH STAGED ONCE PER 32-CHANNEL CHUNK.  The generic body above gathers an im2col A tile per filter tap:
+// nine global -> LDS copies of (almost) the same pixels.  Here the flat NHWC pixel range of a 128*MT-row output tile,
+// widened by W + 1 pixels on both sides (a "flat halo": BM + 2W + 2 consecutive pixels, contiguous in HBM), is loaded
+// once per channel chunk and the nine taps read it at nine row shifts:
+//   tap (dy, dx) of output pixel m  ->  halo row (m - m0) + (W + 1) + dy*W + dx.
+// Where that shift leaves the image (top / bottom row, left / right column, frame boundary) the lane reads a row of
+// zeros instead: the nine per-lane row addresses are loop invariants computed once.  Global -> LDS traffic of the A
+// operand drops by 9*BM / (BM + 2W + 2) (4.8x at W = 56, 6.2x at W = 28 for BM = 128), its load / ds_write instructions
+// and the per-tap address VALU likewise.  Weights stream as before: one (32*NT) x 32 B tile per tap, double buffered.
+// LDS: [BM + 2W + 3 rows] A (one buffer: the next chunk waits in registers) + 2 x [32*NT rows] B, pitch LDT.
+template <int MT, int NT, int EPI, bool RED>
+__device__ __forceinline__ void conv_halo_body(const ConvP& p, const int bid, float* lds) {
+  constexpr int BM = 128 * MT, BN = 32 * NT;
+  constexpr int NJ = (BM + 2 * 64 + 2 + 31) / 32;   // float4 slots per thread for a halo of up to W = 64
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nb = p.tiles_m * p.tiles_n;
+  const int q8 = nb >> 3, r8 = nb & 7, xcd = bid & 7, idx = bid >> 3;
+  const int nid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+  const int tm = nid / p.tiles_n, tn = nid - tm * p.tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int W = p.W, HR = BM + 2 * W + 2;   // halo rows; row HR is the zero row
+  float* As = lds;
+  float* Bs0 = lds + (HR + 1) * LDT;
+
+  const i32x4 in_rsrc = make_rsrc(p.in, p.in_bytes);
+  const i32x4 wt_rsrc = make_rsrc(p.wt, p.wt_bytes);
+  const int c4 = tid & 7, r0 = tid >> 3;
+  const int lrow = lane & 31, lhalf = lane >> 5;
+
+  // per-lane LDS byte address of each tap's A fragment row (or the zero row)
+  unsigned fa_off[MT][9];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int lr = wave * 32 * MT + i * 32 + lrow;
+    const int m = m0 + lr;
+    const uint32_t n = fdiv((uint32_t)m, p.div_ohw);
+    const uint32_t rem = (uint32_t)m - n * p.div_ohw.d;
+    const int y = (int)fdiv(rem, p.div_ow);
+    const int x = (int)rem - y * W;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int dy = t / 3 - 1, dx = t % 3 - 1;
+      const bool ok = (m < p.M) && ((unsigned)(y + dy) < (unsigned)p.H) && ((unsigned)(x + dx) < (unsigned)W);
+      const int row = ok ? lr + (W + 1) + dy * W + dx : HR;
+      fa_off[i][t] = (unsigned)(row * LDT + lhalf * 4) * 4u;
+    }
+  }
+  // halo slot j of this thread: row (tid >> 3) + 32 j, 16-B column c4
+  const int pix0 = m0 - (W + 1) + r0;
+  float4 ha[NJ];
+  auto load_halo = [&](int c0) {
+    const unsigned soff = (unsigned)c0 * 4u;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int h = r0 + 32 * j, pix = pix0 + 32 * j;
+      const bool ok = (h < HR) && ((unsigned)pix < (unsigned)p.M);
+      ha[j] = buf_load4(in_rsrc, ok ? (unsigned)pix * (unsigned)p.in_ld * 4u + (unsigned)c4 * 16u : TBN_OOB, soff);
+    }
+  };
+  auto store_halo = [&]() {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+      if (r0 + 32 * j < HR) *reinterpret_cast<float4*>(&As[(r0 + 32 * j) * LDT + c4 * 4]) = ha[j];
+  };
+  float4 rb[NT];
+  unsigned b_voff[NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+    b_voff[i] = (unsigned)(n0 + r0 + 32 * i) * (unsigned)p.Krow * 4u + (unsigned)c4 * 16u;   // rows >= Cout: beyond wt_bytes
+  auto load_b = [&](int t, int c0) {
+    const unsigned koff = (unsigned)(t * p.Cin + c0) * 4u;
+#pragma unroll
+    for (int i = 0; i < NT; ++i) rb[i] = buf_load4(wt_rsrc, b_voff[i], koff);
+  };
+  auto store_b = [&](float* Bs) {
+#pragma unroll
+    for (int i = 0; i < NT; ++i) *reinterpret_cast<float4*>(&Bs[(r0 + 32 * i) * LDT + c4 * 4]) = rb[i];
+  };
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // prologue: zero row, halo of chunk 0, B tile of (tap 0, chunk 0)
+  load_halo(0);
+  load_b(0, 0);
+  if (tid < LDT) As[HR * LDT + tid] = 0.f;
+  store_halo();
+  store_b(Bs0);
+  __syncthreads();
+
+  const int nchunks = p.Cin >> 5;
+  const char* As_b = reinterpret_cast<const char*>(As);
+  int ks = 0;
+  for (int c = 0; c < nchunks; ++c) {
+    const bool next_chunk = c + 1 < nchunks;
+    if (next_chunk) load_halo((c + 1) * 32);   // nine K-steps to land
+#pragma unroll
+    for (int t = 0; t < 9; ++t, ++ks) {
+      const bool more = next_chunk || t < 8;
+      if (more) load_b(t < 8 ? t + 1 : 0, t < 8 ? c * 32 : (c + 1) * 32);
+      const float* Bs = Bs0 + (ks & 1) * (BN * LDT);
+      float4 fa[2][MT], fb[2][NT];
+      auto frag_load = [&](int buf, int kg) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) fa[buf][i] = *reinterpret_cast<const float4*>(As_b + fa_off[i][t] + kg * 32);
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          fb[buf][j] = *reinterpret_cast<const float4*>(&Bs[(j * 32 + lrow) * LDT + kg * 8 + lhalf * 4]);
+      };
+      auto mfma_group = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int i = 0; i < MT; ++i) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[buf][i].x, fb[buf][j].x, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[buf][i].y, fb[buf][j].y, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[buf][i].z, fb[buf][j].z, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[buf][i].w, fb[buf][j].w, acc[i][j], 0, 0, 0);
+          }
+      };
+      frag_load(0, 0);
+      frag_load(1, 1);
+      mfma_group(0);
+      frag_load(0, 2);
+      mfma_group(1);
+      frag_load(1, 3);
+      mfma_group(0);
+      mfma_group(1);
+      {
+        constexpr int NR = MT + NT, NM = 4 * MT * NT;
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 * NR, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, NR, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, NR, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 2 * NM, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (more) store_b(Bs0 + ((ks + 1) & 1) * (BN * LDT));
+      __syncthreads();
+    }
+    if (next_chunk) {   // every wave is past its last read of this chunk's halo (barrier above)
+      store_halo();
+      __syncthreads();
+    }
+  }
+  conv_epilogue<MT, NT, EPI, RED>(p, acc, lds, tm, m0, n0);
+}
+
+template <int MT, int NT, int EPI, bool RED>
+__global__ __launch_bounds__(256) void conv_halo_kernel(ConvP p) {
+  extern __shared__ __attribute__((aligned(16))) float dyn_lds[];
+  conv_halo_body<MT, NT, EPI, RED>(p, blockIdx.x, dyn_lds);
 }
 
 // The four output-parity phases of a stride-2 data gradient in ONE launch: each phase alone is a small GEMM
@@ -718,6 +890,34 @@ static void launch_conv(const ConvP& p, hipStream_t st) {
     launch_conv_e<MT, NT, RM, 0>(p, st);
 }
 
+// LDS bytes of the halo kernel; 0 if the shape is not a 3x3 / stride 1 / pad 1 layer it handles
+size_t tbn_conv_halo_lds_bytes(const ConvP& p, int mt, int nt) {
+  if (p.R != 3 || p.S != 3 || p.stride != 1 || p.pad != 1 || p.up != 1 || p.OH != p.H || p.OW != p.W || p.W > 64) return 0;
+  return (size_t)(128 * mt + 2 * p.W + 3 + 2 * 32 * nt) * LDT * sizeof(float);
+}
+
+template <int MT, int NT, int EPI, bool RED>
+static int launch_halo_e(const ConvP& p, size_t lds_bytes, hipStream_t st) {
+  static size_t allowed = 64 * 1024;   // per instantiation: raise the dynamic-LDS limit once when a shape needs it
+  if (lds_bytes > allowed) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_kernel<MT, NT, EPI, RED>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+      tbn_set_error("conv_halo: cannot raise the dynamic LDS limit");
+      return TBN_ERR_LAUNCH;
+    }
+    allowed = 160 * 1024;
+  }
+  hipLaunchKernelGGL((conv_halo_kernel<MT, NT, EPI, RED>), dim3(p.tiles_m * p.tiles_n), dim3(256), lds_bytes, st, p);
+  return TBN_OK;
+}
+template <int MT, int NT>
+static int launch_halo(const ConvP& p, size_t lds_bytes, hipStream_t st) {
+  if (p.mode == CONV_EPI_STATS) return launch_halo_e<MT, NT, 1, false>(p, lds_bytes, st);
+  if (p.mode == CONV_EPI_EVAL) return launch_halo_e<MT, NT, 2, false>(p, lds_bytes, st);
+  if (p.nred > 0) return launch_halo_e<MT, NT, 0, true>(p, lds_bytes, st);
+  return launch_halo_e<MT, NT, 0, false>(p, lds_bytes, st);
+}
+
 void tbn_conv_pick_tile(int M, int Cout, int K, int* mt_out, int* nt_out) {
   double best = 1e300;
   int bm = 1, bn = 1;
@@ -759,6 +959,24 @@ static int launch_conv_tiles(ConvP& p, int rowmode, int mt, int nt, hipStream_t 
   if (p.stages != 1 && p.stages != 2) p.stages = (mt == 1) ? 2 : 1;  // big tiles: keep 2 workgroups per CU
   p.tiles_m = cdiv(p.M, 128 * mt);
   p.tiles_n = cdiv(p.Cout, 32 * nt);
+  if (p.halo && !rowmode) {
+    const size_t lds_bytes = tbn_conv_halo_lds_bytes(p, mt, nt);
+    TBN_REQUIRE(lds_bytes > 0 && lds_bytes <= 160 * 1024, "conv: the LDS-halo kernel does not handle this shape / tile");
+    TBN_REQUIRE(mt <= 2 && nt <= 4, "conv: unsupported halo tile %dx%d", mt, nt);
+    char nm[64];
+    const int epi = p.mode == CONV_EPI_STATS ? 1 : (p.mode == CONV_EPI_EVAL ? 2 : 0);
+    snprintf(nm, sizeof(nm), "conv_halo_kernel<%d, %d, %d%s>", mt, nt, epi, (p.nred > 0 && epi == 0) ? ", true" : "");
+    tbn_prof_begin(nm, p.alg_flops, st);
+    int rc = TBN_OK;
+#define TBN_HCASE(MTv, NTv) \
+  if (mt == MTv && nt == NTv) rc = launch_halo<MTv, NTv>(p, lds_bytes, st);
+    TBN_HCASE(1, 1) TBN_HCASE(1, 2) TBN_HCASE(1, 3) TBN_HCASE(1, 4) TBN_HCASE(2, 1) TBN_HCASE(2, 2) TBN_HCASE(2, 3) TBN_HCASE(2, 4)
+#undef TBN_HCASE
+    tbn_prof_end(st);
+    if (rc != TBN_OK) return rc;
+    TBN_CHECK_LAUNCH("conv_halo");
+    return TBN_OK;
+  }
   {
     char nm[64];
     const int epi = p.mode == CONV_EPI_STATS ? 1 : (p.mode == CONV_EPI_EVAL ? 2 : ((p.out_sy != 1 || p.out_sx != 1) ? 3 : 0));
@@ -806,6 +1024,7 @@ int tbn_launch_conv(ConvP p, int rowmode, int mt, int nt, hipStream_t st) {
     }
   }
   TBN_REQUIRE(p.up == 1 || p.up == 2, "conv: up must be 1 or 2");
+  if (p.flags & CONV_FLAG_HALO) p.halo = 1;
   TBN_REQUIRE(p.M > 0, "conv: empty problem");
   const size_t in_bytes = (size_t)p.N * p.H * p.W * (rowmode ? p.cp : p.in_ld) * sizeof(float);
   TBN_REQUIRE(in_bytes < (1ull << 31), "conv: input extent %zu B >= 2 GiB (process the frames in chunks)", in_bytes);

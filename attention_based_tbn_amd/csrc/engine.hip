@@ -74,6 +74,7 @@ struct Conv {   // one GEMM: up to four parts that read the same input (adjacent
   int slot = 0;                 // forward statistics scratch slot
   int mt, nt, stages = 0;       // forward tile / LDS stages (0 = default)
   int d_mt, d_nt, d_stages = 0; // dgrad tile
+  int halo = 0, d_halo = 0;     // 3x3 / stride-1 layers: LDS-halo kernel for the forward / data-gradient GEMM
   int w_mt = 0, w_nt = 0;       // wgrad tile (0 = heuristic)
   bool stem;
   bool dgrad_accum;    // dgrad adds into d(inbuf)
@@ -704,6 +705,7 @@ void fill_fwd(const tbn_backbone_plan* P, const Conv& c, float* ws, const float*
     p.K = c.k * c.k * c.cin;
   }
   p.stages = c.stages;
+  p.halo = c.halo;
 }
 
 // data-gradient launch parameters of one GEMM: conv of dy with flipped / transposed weights (parity phases for
@@ -736,6 +738,7 @@ void fill_dgrad(const tbn_backbone_plan* P, const Conv& c, float* ws, int R, Con
   p.seg[0].ld = ib.C;
   p.seg[0].col_begin = 0;
   p.stages = c.d_stages;
+  p.halo = c.d_halo;
   p.nred = c.nred;
   p.red_chan = (int)P->chan_floats;
   for (int k = 0; k < c.nred; ++k) {
@@ -1024,11 +1027,19 @@ int tbn_backbone_autotune(tbn_backbone_plan* P, int training, const tbn_backbone
       // within 3-15 % of the fastest -- monotonically slower steps; autotuning the weight-gradient tile the same
       // way -- 0.4 % slower than the size heuristic of tbn_wgrad_plan.)
       float best = 1e30f;
-      int bm = 1, bn = 1, bs = 2;
+      int bm = 1, bn = 1, bs = 2, bh = 0;
+      static const int force_halo = getenv("TBN_FORCE_HALO") ? atoi(getenv("TBN_FORCE_HALO")) : -1;   // tests: 0 / 1
       for (int mt = 1; mt <= 2 && rc == TBN_OK; ++mt)
         for (int nt = 1; nt <= 4 && rc == TBN_OK; ++nt)
-          for (int stg = 1; stg <= 2 && rc == TBN_OK; ++stg) {
+          for (int stg = 0; stg <= 2 && rc == TBN_OK; ++stg) {   // 0: the LDS-halo kernel (3x3 / stride-1 layers)
             if (32 * (nt - 1) >= p.Cout) continue;
+            p.halo = stg == 0;
+            if (p.halo) {
+              const size_t lb = (c.stem && pass == 0) ? 0 : tbn_conv_halo_lds_bytes(p, mt, nt);
+              if (lb == 0 || lb > 160 * 1024 || force_halo == 0) continue;
+            } else if (force_halo == 1 && !(c.stem && pass == 0) && tbn_conv_halo_lds_bytes(p, 1, 1) > 0) {
+              continue;
+            }
             float ms = 0.f;
             p.stages = stg;
             for (int rep = 0; rep < 2 && rc == TBN_OK; ++rep) {
@@ -1043,16 +1054,19 @@ int tbn_backbone_autotune(tbn_backbone_plan* P, int training, const tbn_backbone
               bm = mt;
               bn = nt;
               bs = stg;
+              bh = p.halo;
             }
           }
       if (pass == 0) {
         c.mt = bm;
         c.nt = bn;
         c.stages = bs;
+        c.halo = bh;
       } else {
         c.d_mt = bm;
         c.d_nt = bn;
         c.d_stages = bs;
+        c.d_halo = bh;
       }
     }
     if (rc != TBN_OK) break;

@@ -3,7 +3,7 @@
 #include "tbn_common.h"
 
 enum { CONV_EPI_PLAIN = 0, CONV_EPI_STATS = 1, CONV_EPI_EVAL = 2 };
-enum { CONV_FLAG_ACCUM = 1, CONV_FLAG_RELU = 2 };
+enum { CONV_FLAG_ACCUM = 1, CONV_FLAG_RELU = 2, CONV_FLAG_HALO = 4 /* host only: use the LDS-halo kernel */ };
 
 // BN-backward reduce fused into a data-gradient epilogue (the launch that writes the FINAL value of dz): for the output
 // columns [col_begin, col_begin + C) -- one BN layer of the producer side -- the epilogue forms
@@ -47,6 +47,7 @@ struct ConvP {
   int mode, flags;
   double alg_flops;       // host only: algorithmic FLOPs of this launch (profiling)
   int stages;             // host only: LDS stages (1 = two barriers per K-step, 2 = double buffered); 0 = default
+  int halo;               // host only: 1 = LDS-halo kernel (3x3 / stride 1 / pad 1 layers: input patch staged once per chunk)
   // ---- derived by tbn_launch_conv
   unsigned in_bytes, wt_bytes;          // buffer extents: out-of-range lanes read zeros (hardware check)
   unsigned seg_bytes[TBN_CONV_MAXSEG];  // extent of each output segment from seg[i].ptr
@@ -91,6 +92,7 @@ void tbn_prof_label(const char* label);
 void tbn_conv_pick_tile(int M, int Cout, int K, int* mt, int* nt);
 int tbn_launch_conv(ConvP p, int rowmode, int mt, int nt, hipStream_t st);
 int tbn_conv_red_rows(int N, int OH, int OW, int up, int mt);
+size_t tbn_conv_halo_lds_bytes(const ConvP& p, int mt, int nt);   // 0: shape not handled by the LDS-halo kernel
 void tbn_wgrad_plan(int M, int Cout, int Cin, int taps, int* mt, int* nt, int* splits, int* rows_per_split);
 size_t tbn_wgrad_workspace_floats(int M, int Cout, int Cin, int taps);
 int tbn_launch_wgrad(WgradP p, int rowmode, float* dw, float* workspace, hipStream_t st);

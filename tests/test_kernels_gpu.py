@@ -121,6 +121,54 @@ def test_conv2d_fwd_dgrad_wgrad(case):
     assert relerr(dw.permute(0, 3, 1, 2), wr.grad) < TOL
 
 
+HALO_CASES = [
+    # n, h, w, cin, cout: 3x3 / stride 1 / pad 1 layers (ragged M tiles, frame boundaries inside a tile, W up to 64,
+    # maps narrower than a tile row, Cout not a multiple of the N tile)
+    (2, 14, 14, 64, 96), (3, 7, 7, 192, 320), (1, 28, 28, 96, 96), (2, 9, 11, 32, 160), (5, 3, 3, 64, 32),
+    (1, 56, 56, 64, 192), (1, 5, 64, 32, 64), (3, 4, 16, 160, 192), (2, 17, 13, 96, 224),
+]
+
+
+@pytest.mark.parametrize("case", HALO_CASES)
+def test_conv3x3_halo_kernel_all_tiles(case):
+    """the LDS-halo 3x3 kernel (input patch staged once per channel chunk, taps = row shifts inside LDS) against
+    fp64 conv2d: every (MT, NT) tile, plain / BN-statistics / eval epilogues, and as data gradient"""
+    n, h, w, cin, cout = case
+    k, s, p = 3, 1, 1
+    x = torch.randn(n, cin, h, w, generator=g(11))
+    wt = torch.randn(cout, cin, k, k, generator=g(12)) / (cin * 9) ** 0.5
+    b = torch.randn(cout, generator=g(13))
+    y_ref = F.conv2d(x.double(), wt.double(), None, stride=1, padding=1)
+    xd, wd, bd = nhwc(x).to(DEV), wt.permute(0, 2, 3, 1).contiguous().to(DEV), b.to(DEV)
+    HALO = 4
+    for mt in (1, 2):
+        for nt in (1, 2, 3, 4):
+            if 32 * (nt - 1) >= cout:
+                continue
+            y = torch.full((n, h, w, cout + 32), 3.0, device=DEV)
+            call("tbn_conv2d_fwd_tile", ptr(xd), cin, ptr(wd), ptr(bd), y.data_ptr() + 16 * 4, cout + 32, n, h, w, cin,
+                 cout, k, s, p, 0, HALO, 0, mt, nt, st())
+            assert relerr(nchw(y[..., 16:16 + cout]), y_ref + b.double().view(1, -1, 1, 1)) < TOL, (mt, nt)
+            assert float((y[..., :16] - 3).abs().max()) == 0 and float((y[..., 16 + cout:] - 3).abs().max()) == 0
+            tiles = (n * h * w + 128 * mt - 1) // (128 * mt)
+            part = torch.zeros(tiles, 2, cout, device=DEV)
+            yb = torch.empty(n, h, w, cout, device=DEV)
+            call("tbn_conv2d_fwd_tile", ptr(xd), cin, ptr(wd), ptr(bd), ptr(yb), cout, n, h, w, cin, cout, k, s, p, 1,
+                 HALO, ptr(part), mt, nt, st())
+            assert relerr(nchw(yb), y_ref) < TOL, (mt, nt)
+            assert relerr(part[:, 0].double().sum(0).cpu(), y_ref.sum((0, 2, 3))) < TOL
+            assert relerr(part[:, 1].double().sum(0).cpu(), (y_ref * y_ref).sum((0, 2, 3))) < TOL
+
+
+def test_conv3x3_halo_rejects_other_shapes():
+    from attention_based_tbn_amd._lib import lib as _lib
+    x = torch.zeros(1, 8, 8, 32, device=DEV)
+    wt = torch.zeros(32, 1, 1, 32, device=DEV)
+    y = torch.zeros(1, 8, 8, 32, device=DEV)
+    rc = _lib().tbn_conv2d_fwd_tile(ptr(x), 32, ptr(wt), None, ptr(y), 32, 1, 8, 8, 32, 32, 1, 1, 0, 0, 4, None, 1, 1, st())
+    assert rc < 0 and b"LDS-halo" in _lib().tbn_last_error()
+
+
 def _fuzz_cases(count, seed):
     """seeded random conv geometries inside the kernels' documented domain (channels in multiples of 32, 1x1 / 3x3,
     stride 1 / 2, any padding < k, ragged maps) -- none of them a BN-Inception layer shape"""
