@@ -401,7 +401,9 @@ bool build_graph(tbn_backbone_plan* P) {
   std::vector<int> readers(P->bufs.size(), 0);
   for (auto& c : P->convs) ++readers[c.inbuf];
   for (auto& q : P->pools) ++readers[q.inbuf];
-  for (size_t pi = 0; pi < P->pools.size(); ++pi) {
+  // TBN_NO_FUSE_POOL=1 (tests): keep the stem pools as separate kernels so that every z tensor exists in the workspace
+  const bool no_fuse = getenv("TBN_NO_FUSE_POOL") != nullptr && atoi(getenv("TBN_NO_FUSE_POOL")) != 0;
+  for (size_t pi = 0; pi < P->pools.size() && !no_fuse; ++pi) {
     Pool& q = P->pools[pi];
     if (q.kind != 1 || q.bwd_accum || readers[q.inbuf] != 1 || q.inbuf == P->out_buf) continue;
     for (auto& c : P->convs)
@@ -619,7 +621,8 @@ int tbn_backbone_conv_info(const tbn_backbone_plan* P, int idx, tbn_conv_info* i
 
 // debugging / per-layer parity tests: where one conv's tensors live inside the workspace.
 // kind 0: z = relu(bn(conv)) destination slice; 1: BN input y (after backward: dy);
-// 2: gradient wrt z.  offset in floats (for kind 2 of the final block the gradient is external: -1).
+// 2: gradient wrt z (for the final block the gradient is external: -1); 3: the conv's whole INPUT buffer (a block's
+// concat buffer / a pool output).  offset in floats.
 int tbn_backbone_tensor_info(const tbn_backbone_plan* P, const char* conv_name, int kind, long* offset, int* rows,
                              int* cols, int* ld) {
   for (auto& c : P->convs)
@@ -629,6 +632,13 @@ int tbn_backbone_tensor_info(const tbn_backbone_plan* P, const char* conv_name, 
       const Buf& db = P->bufs[q.dst_buf];
       *rows = P->frames * c.outH * c.outW;
       *cols = q.cout;
+      if (kind == 3) {
+        const Buf& ib = P->bufs[c.inbuf];
+        *offset = (long)ib.off;
+        *rows = P->frames * c.inH * c.inW;
+        *cols = *ld = ib.C;
+        return TBN_OK;
+      }
       if (kind == 1) {
         *offset = (long)(q.pooled ? q.y2_off : c.y_off + q.col0);
         *ld = q.pooled ? q.cout : c.cout;

@@ -4,77 +4,98 @@
 //
 // Only 239 of the 511 window taps are non-zero (periodic Hann(240), centred), so a frame's 256
 // bins are a dense 256 x 240 real DFT: X[k] = sum_j hann[j] * y[120 t - 120 + j] * e^{-2 pi i (j+135) k / 511}.
-// That is a [bins x taps] x [taps x frames] contraction -> fp32 MFMA (32x32x2), with the window
-// folded into a twiddle table (host fp64 -> fp32, 2 x 256 taps x 256 bins, L2 resident).
-// One workgroup = 32 frames x 256 bins of one segment; frames are staged as an im2col tile in LDS
-// ([32][257] -> conflict-free column reads); the accumulator layout puts frames on lanes so the
-// (256, W) freq-major output rows are written 128 B contiguous.
+// That is a [bins x taps] x [taps x frames] contraction -> fp32 MFMA (32x32x2), 2 * 2 * 256 * 240 FLOP per frame.
+//
+// Workgroup = 128 bins x 64 frames of one segment (4 waves x 32 bins; re and im of 2 frame tiles = 4 accumulators).
+//   * frames (B operand): hop = 120, 240 taps -> consecutive frames overlap by half.  The RAW samples of the 64
+//     frames (65 hop rows of 120) are staged once in LDS with rows padded to 124 floats: frame f, tap j lives at
+//     (f + j / 120) * 124 + j % 120, no im2col copy, and a lane's four consecutive taps are one conflict-free
+//     ds_read_b128 (lane stride 496 B -> 16 distinct 16-B slots per 16-lane group);
+//   * twiddles (A operand): the window is folded into the table, stored [cos | -sin][tap / 8][bin][tap % 8]: the
+//     fragment of 8 taps x 32 bins is ONE fully coalesced 1-KB load per wave (the table is 480 KB, shared by every
+//     workgroup: L2 resident), prefetched one 8-tap group ahead; each load feeds 8 MFMAs;
+//   * k is permuted identically for A and B (lane half h holds taps 4h..4h+3 of the group) so one 16-B fragment
+//     feeds four MFMAs; accumulators put frames on lanes -> the (256, W) freq-major rows are written 128 B contiguous.
 #include <cmath>
 #include <cstring>
 
 #include "tbn_common.h"
 #include "../../include/tbn_hip.h"
 
-#define STFT_TAPS 256  // 240 real taps, zero padded
+#define STFT_TAPS 240
+#define STFT_KG 30     // groups of 8 taps
 #define STFT_BINS 256
+#define STFT_FR 64     // frames per workgroup
+#define STFT_PITCH 124 // LDS floats per hop row of 120 samples
 
 __global__ __launch_bounds__(256) void stft_logpower_kernel(const float* __restrict__ wave, int len, int W,
                                                             const float* __restrict__ tw, float* __restrict__ spec,
                                                             float eps) {
-  __shared__ float fr[32 * 257];
-  const int seg = blockIdx.y, t0 = blockIdx.x * 32;
+  __shared__ __attribute__((aligned(16))) float fr[(STFT_FR + 1) * STFT_PITCH];
+  const int seg = blockIdx.y, t0 = blockIdx.x * STFT_FR;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const float* y = wave + (size_t)seg * len;
-  for (int i = tid; i < 32 * 256; i += 256) {
-    const int f = i >> 8, j = i & 255;
-    const int idx = (t0 + f) * 120 - 120 + j;
-    fr[f * 257 + j] = (j < 240 && idx >= 0 && idx < len) ? y[idx] : 0.f;
-  }
-  __syncthreads();
-  const float* tc = tw;                           // [tap][bin] hann*cos
-  const float* ts = tw + STFT_TAPS * STFT_BINS;   // [tap][bin] -hann*sin
   const int lrow = lane & 31, lhalf = lane >> 5;
-  const int b0 = wv * 64;
+  const int b0 = blockIdx.z * 128 + wv * 32;
+  const float* y = wave + (size_t)seg * len;
+  const int g0 = (t0 - 1) * 120;
+  for (int i = tid; i < (STFT_FR + 1) * 120; i += 256) {
+    const int r = i / 120, c = i - r * 120;
+    const int g = g0 + i;
+    fr[r * STFT_PITCH + c] = (g >= 0 && g < len) ? y[g] : 0.f;
+  }
+  // twiddle fragment of tap group kg: 16 B at [part][kg][b0 + lrow][4 * lhalf]
+  const float4* twc = reinterpret_cast<const float4*>(tw) + ((size_t)(b0 + lrow) * 2 + lhalf);
+  const size_t part4 = (size_t)STFT_KG * STFT_BINS * 2;   // float4 per table
   f32x16 re0, im0, re1, im1;
 #pragma unroll
   for (int e = 0; e < 16; ++e) re0[e] = im0[e] = re1[e] = im1[e] = 0.f;
-  for (int s = 0; s < 120; ++s) {
-    const int tap = 2 * s + lhalf;
-    const float b = fr[lrow * 257 + tap];
-    const float c0 = tc[tap * STFT_BINS + b0 + lrow], s0 = ts[tap * STFT_BINS + b0 + lrow];
-    const float c1 = tc[tap * STFT_BINS + b0 + 32 + lrow], s1 = ts[tap * STFT_BINS + b0 + 32 + lrow];
-    re0 = __builtin_amdgcn_mfma_f32_32x32x2f32(c0, b, re0, 0, 0, 0);
-    im0 = __builtin_amdgcn_mfma_f32_32x32x2f32(s0, b, im0, 0, 0, 0);
-    re1 = __builtin_amdgcn_mfma_f32_32x32x2f32(c1, b, re1, 0, 0, 0);
-    im1 = __builtin_amdgcn_mfma_f32_32x32x2f32(s1, b, im1, 0, 0, 0);
-  }
-  const int t = t0 + lrow;
-  if (t < W) {
-    float* o = spec + (size_t)seg * STFT_BINS * W + t;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int row = 8 * (e >> 2) + 4 * lhalf + (e & 3);
-      o[(size_t)(b0 + row) * W] = logf(re0[e] * re0[e] + im0[e] * im0[e] + eps);
-      o[(size_t)(b0 + 32 + row) * W] = logf(re1[e] * re1[e] + im1[e] * im1[e] + eps);
+  float4 ac = twc[0], as = twc[part4];
+  __syncthreads();
+#pragma unroll 2
+  for (int kg = 0; kg < STFT_KG; ++kg) {
+    const float4 c = ac, s = as;
+    if (kg + 1 < STFT_KG) {
+      ac = twc[(size_t)(kg + 1) * STFT_BINS * 2];
+      as = twc[part4 + (size_t)(kg + 1) * STFT_BINS * 2];
     }
+    const int tap0 = kg * 8 + 4 * lhalf;
+    const int off = (lrow + (tap0 >= 120 ? 1 : 0)) * STFT_PITCH + (tap0 >= 120 ? tap0 - 120 : tap0);
+    const float4 f0 = *reinterpret_cast<const float4*>(&fr[off]);
+    const float4 f1 = *reinterpret_cast<const float4*>(&fr[off + 32 * STFT_PITCH]);
+#define STFT_STEP(q)                                                         \
+    re0 = __builtin_amdgcn_mfma_f32_32x32x2f32(c.q, f0.q, re0, 0, 0, 0);      \
+    im0 = __builtin_amdgcn_mfma_f32_32x32x2f32(s.q, f0.q, im0, 0, 0, 0);      \
+    re1 = __builtin_amdgcn_mfma_f32_32x32x2f32(c.q, f1.q, re1, 0, 0, 0);      \
+    im1 = __builtin_amdgcn_mfma_f32_32x32x2f32(s.q, f1.q, im1, 0, 0, 0);
+    STFT_STEP(x) STFT_STEP(y) STFT_STEP(z) STFT_STEP(w)
+#undef STFT_STEP
+  }
+  float* o = spec + (size_t)seg * STFT_BINS * W;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int bin = b0 + 8 * (e >> 2) + 4 * lhalf + (e & 3);
+    const int ta = t0 + lrow, tb = t0 + 32 + lrow;
+    if (ta < W) o[(size_t)bin * W + ta] = logf(re0[e] * re0[e] + im0[e] * im0[e] + eps);
+    if (tb < W) o[(size_t)bin * W + tb] = logf(re1[e] * re1[e] + im1[e] * im1[e] + eps);
   }
 }
 
 extern "C" {
 
-size_t tbn_stft_twiddle_floats(void) { return (size_t)2 * STFT_TAPS * STFT_BINS; }
+size_t tbn_stft_twiddle_floats(void) { return (size_t)2 * STFT_KG * STFT_BINS * 8; }
 
 int tbn_stft_make_twiddle(float* host) {
   TBN_REQUIRE(host != nullptr, "stft_make_twiddle: null buffer");
-  memset(host, 0, tbn_stft_twiddle_floats() * sizeof(float));
   const double pi = 3.14159265358979323846;
-  for (int j = 0; j < 240; ++j) {
+  const size_t part = (size_t)STFT_KG * STFT_BINS * 8;
+  for (int j = 0; j < STFT_TAPS; ++j) {
     const double h = 0.5 - 0.5 * cos(2.0 * pi * j / 240.0);
     for (int k = 0; k < STFT_BINS; ++k) {
       const long m = ((long)(j + 135) * k) % 511;  // exact phase reduction
       const double a = 2.0 * pi * (double)m / 511.0;
-      host[j * STFT_BINS + k] = (float)(h * cos(a));
-      host[STFT_TAPS * STFT_BINS + j * STFT_BINS + k] = (float)(-h * sin(a));
+      const size_t idx = ((size_t)(j / 8) * STFT_BINS + k) * 8 + (j % 8);
+      host[idx] = (float)(h * cos(a));
+      host[part + idx] = (float)(-h * sin(a));
     }
   }
   return TBN_OK;
@@ -85,8 +106,8 @@ int tbn_stft_logpower(const float* wave, int nseg, int len, const float* twiddle
   TBN_REQUIRE(wave && twiddle && spec && nseg > 0 && len > 0, "stft_logpower: bad argument");
   TBN_REQUIRE(nseg <= 65535, "stft_logpower: too many segments per call");
   const int W = 1 + (len - 1) / 120;
-  hipLaunchKernelGGL(stft_logpower_kernel, dim3(cdiv(W, 32), nseg), dim3(256), 0, (hipStream_t)stream, wave, len, W,
-                     twiddle, spec, eps);
+  hipLaunchKernelGGL(stft_logpower_kernel, dim3(cdiv(W, STFT_FR), nseg, 2), dim3(256), 0, (hipStream_t)stream, wave,
+                     len, W, twiddle, spec, eps);
   TBN_CHECK_LAUNCH("stft_logpower");
   return TBN_OK;
 }

@@ -141,6 +141,9 @@ def main():
     ap.add_argument("--host-inputs", action="store_true",
                     help="diagnostic (never the headline): the batch starts in pinned HOST memory every step and is copied "
                          "over PCIe on a side stream, double-buffered against the previous step -- the PCIe-inclusive rate")
+    ap.add_argument("--stft-inputs", action="store_true",
+                    help="the audio leg starts from WAVEFORMS (B, n, 30695 samples = 1.279 s at 24 kHz, resident in HBM): the "
+                         "log-power STFT kernel (reference dataset.py:483-495, CPU librosa there) runs inside the timed step")
     ap.add_argument("--profile-every", type=int, default=1 << 30,
                     help="bracket conv-GEMM launches with HIP events on every k-th timed step (default: the first "
                          "timed step only; 0 = never).  Profiled steps run single-stream, see DESIGN.md")
@@ -202,6 +205,14 @@ def main():
     if C_["train"] and args.forward_only:
         flop_per_clip = {2: 12.190, 3: 37.108 if args.audio_2p1s else 27.494, 4: 41.336}[args.config] * 1e9
 
+    wave, spectrogram = None, None
+    if args.stft_inputs:
+        assert "Audio" in modality and audio_w == 256, "--stft-inputs: 1.279 s audio configs"
+        from attention_based_tbn_amd.core.dataset import Spectrogram
+        spectrogram = Spectrogram()
+        gw = torch.Generator(device=device).manual_seed(1000 + rank)
+        wave = 0.1 * torch.randn(B * n, 30695, device=device, generator=gw)      # 0.1 * N(0, 1)
+
     def eval_step():
         with torch.no_grad():
             out = model(inp)
@@ -234,6 +245,8 @@ def main():
                 bufs[k].record_stream(torch.cuda.current_stream())
             inp.update(bufs)
             stage()
+        if wave is not None:          # waveform -> (B, n, 1, 256, 256) log-power spectrogram on the GPU, every step
+            inp["Audio"] = spectrogram(wave).view(B, n, 1, 256, 256)
         if not C_["train"]:
             return eval_step()
         if args.forward_only:
@@ -319,7 +332,8 @@ def main():
             "config": {"workload": C_["name"] + (" [forward only]" if args.forward_only and C_["train"] else ""),
                        "batch_per_gpu": B, "global_batch": B * world, "segments": n,
                        "parallelism": f"dp{world}" if world > 1 else "single",
-                       **({"inputs": "pinned host memory, PCIe copy every step (diagnostic)"} if args.host_inputs else {})},
+                       **({"inputs": "pinned host memory, PCIe copy every step (diagnostic)"} if args.host_inputs else {}),
+                       **({"audio_input": "waveform (30695 samples), STFT kernel inside the timed step"} if args.stft_inputs else {})},
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline and args.config == 4 and not args.forward_only:

@@ -85,8 +85,8 @@ size_t tbn_backbone_channel_floats(const tbn_backbone_plan* plan);
 size_t tbn_backbone_workspace_bytes(const tbn_backbone_plan* plan, int training);
 int tbn_backbone_out_shape(const tbn_backbone_plan* plan, int* h, int* w, int* c);
 /* test / debug aid: location of one conv's tensors inside the workspace (floats). kind 0: z =
- * relu(bn(conv)) destination slice, 1: raw conv output y (overwritten by dy in backward), 2: gradient
- * wrt z (offset -1 when it is the caller-supplied dfeatures). */
+ * relu(bn(conv)) destination slice, 1: BN input y (overwritten by dy in backward), 2: gradient
+ * wrt z (offset -1 when it is the caller-supplied dfeatures), 3: the conv's whole input buffer. */
 int tbn_backbone_tensor_info(const tbn_backbone_plan* plan, const char* conv_name, int kind, long* offset, int* rows,
                              int* cols, int* ld);
 /* x_nchw: (frames, in_channels, H, W) contiguous, as the reference passes it (model.py:213).

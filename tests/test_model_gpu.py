@@ -306,6 +306,135 @@ def test_backbone_all_layer_grads_vs_oracle(cin_hw):
             assert rel_err(f.cpu(), ora.features(x)) < 1e-3 and rel_err(net.logits(f).cpu(), b2) < 1e-3
 
 
+class _ForcedReLU(torch.nn.Module):
+    """ReLU whose on/off decisions come from another run (here: the HIP product's z > 0)"""
+
+    def __init__(self, mask_rows):
+        super().__init__()
+        self.mask_rows = mask_rows            # (N*H*W, C) bool, NHWC pixel order
+
+    def forward(self, x):
+        n, c, h, w = x.shape
+        return x * self.mask_rows.view(n, h, w, c).permute(0, 3, 1, 2).to(x.dtype)
+
+
+class _ForcedMaxPool(torch.nn.Module):
+    """3x3 max pool that routes through the window entry ANOTHER run selected: the entry of the product's own fp32
+    input that equals the product's pooled value (first in scan order, the engine's tie rule)"""
+
+    def __init__(self, pool, x32, out32):
+        super().__init__()
+        import torch.nn.functional as F
+        s = pool.stride if isinstance(pool.stride, int) else pool.stride[0]
+        p = pool.padding if isinstance(pool.padding, int) else pool.padding[0]
+        n, c, h, w = x32.shape
+        oh, ow = out32.shape[2:]
+        pb, pr = max(0, (oh - 1) * s + 3 - h - p), max(0, (ow - 1) * s + 3 - w - p)
+        xp = F.pad(x32, (p, pr, p, pb), value=float("-inf"))
+        win = F.unfold(xp, 3, stride=s).view(n, c, 9, oh * ow)
+        eq = win == out32.reshape(n, c, 1, oh * ow)
+        assert bool(eq.any(2).all()), "pooled value not found in its window"
+        k = eq.float().argmax(2)                                          # first match
+        oy = torch.arange(oh).repeat_interleave(ow).view(1, 1, -1)
+        ox = torch.arange(ow).repeat(oh).view(1, 1, -1)
+        self.idx = (oy * s - p + k // 3) * w + (ox * s - p + k % 3)
+        self.out_hw = (oh, ow)
+
+    def forward(self, x):
+        n, c = x.shape[:2]
+        return x.flatten(2).gather(2, self.idx).view(n, c, *self.out_hw)
+
+
+@pytest.mark.parametrize("cin_hw", [(3, 96, 96), (10, 96, 96), (1, 96, 96), (10, 70, 129), (3, 224, 224)])
+def test_backbone_all_layer_grads_forced_decisions(cin_hw, monkeypatch):
+    """EVERY conv / BN parameter gradient of a backbone within 1e-3 relative L2 of an fp64 reference (observed: 1e-5 to
+    1e-4).  The fp32 training-mode backward is ill conditioned: some ReLU input or max-pool runner-up always lies
+    within the fp32 error of its decision boundary (tests/golden/make_tight_seeds.py: best safety over 300 seeds 1.3
+    fp32-error units), and ONE flipped decision in a 3x3 map moves every upstream gradient by percents -- in torch's own
+    fp32 CPU path exactly as here.  So the fp64 oracle is made to take the PRODUCT's decisions: its ReLUs multiply by the
+    product's (z > 0) masks, its max pools route through the entry the product selected (both read back from the
+    engine workspace), and everything else -- convolutions, batch statistics, the whole backward -- is the oracle's own
+    fp64 arithmetic.  What remains is the arithmetic error of the 69 weight-gradient / data-gradient / BN-backward
+    steps: merged 1x1 groups, reduce-in-epilogue, parity-phase strided gradients, LDS-halo 3x3 kernels included.
+    (Pool fusion of the stem is switched off for this plan so that every z exists in memory; the fused stem kernels
+    keep their own parity tests.)"""
+    import copy
+    import ctypes as C
+    from oracle.bninception import BNInception as OBN
+    from oracle.fill import fill_state_dict
+    from attention_based_tbn_amd._lib import call
+    from attention_based_tbn_amd.core.models.bn_inception import BNInception
+    cin, H, W = cin_hw
+    N = 2
+    monkeypatch.setenv("TBN_NO_FUSE_POOL", "1")
+    ora = OBN(1000, cin)
+    sd = fill_state_dict(ora.state_dict(), 42)
+    ora.load_state_dict(sd)
+    o64 = copy.deepcopy(ora).double().train()
+    net = BNInception(1000, cin).to(DEV)
+    net.load_state_dict(sd)
+    net.train()
+    x = torch.randn(N, cin, H, W, generator=torch.Generator().manual_seed(5))
+    y = net(x.to(DEV))
+    plan = net._plans[(N, H, W)]
+    ws = plan.pool[0][0].view(torch.float32)
+
+    def tensor(name, kind):
+        off, rows, cols, ld = C.c_long(), C.c_int(), C.c_int(), C.c_int()
+        call("tbn_backbone_tensor_info", plan.handle, name.encode(), kind, C.byref(off), C.byref(rows), C.byref(cols),
+             C.byref(ld))
+        return torch.as_strided(ws, (rows.value, cols.value), (ld.value, 1), off.value).cpu()
+
+    def nchw(rows, like_hw):
+        h, w = like_hw
+        return rows.view(N, h, w, -1).permute(0, 3, 1, 2).contiguous()
+
+    # the product's decisions -> the fp64 oracle
+    names = [n for n, m in o64.named_children() if isinstance(m, torch.nn.Conv2d)]
+    relus = [n for n, m in o64.named_children() if isinstance(m, torch.nn.ReLU)]
+    assert len(names) == len(relus) == 69
+    for cname, rname in zip(names, relus):
+        setattr(o64, rname, _ForcedReLU(tensor(cname, 0) > 0))
+    shapes = {}
+    hooks = [m.register_forward_pre_hook(lambda mod, inp, k=k: shapes.__setitem__(k, inp[0].shape[2:]))
+             for k, m in ora.named_children() if isinstance(m, torch.nn.MaxPool2d)]
+    hooks += [m.register_forward_hook(lambda mod, inp, out, k=k: shapes.__setitem__(k + "_out", out.shape[2:]))
+              for k, m in ora.named_children() if isinstance(m, torch.nn.MaxPool2d)]
+    with torch.no_grad():
+        ora.train()(x)
+    for h in hooks:
+        h.remove()
+    pools = {
+        "pool1_3x3_s2": (tensor("conv1_7x7_s2", 0), tensor("conv2_3x3_reduce", 3)),
+        "pool2_3x3_s2": (tensor("conv2_3x3", 0), tensor("inception_3a_1x1", 3)),
+        "inception_3c_pool": (tensor("inception_3c_3x3_reduce", 3), tensor("inception_4a_1x1", 3)[:, 256:576]),
+        "inception_4e_pool": (tensor("inception_4e_3x3_reduce", 3), tensor("inception_5a_1x1", 3)[:, 448:1056]),
+        "inception_5b_pool": (tensor("inception_5b_1x1", 3), tensor("inception_5b_pool_proj", 3)),
+    }
+    for pname, (xin, xout) in pools.items():
+        setattr(o64, pname, _ForcedMaxPool(getattr(ora, pname), nchw(xin, shapes[pname]), nchw(xout, shapes[pname + "_out"])))
+    y64 = o64(x.double())
+    dy = torch.randn(y64.shape, generator=torch.Generator().manual_seed(2))
+    y64.backward(dy.double())
+    y.backward(dy.to(DEV))
+    assert rel_err(y.detach().cpu(), y64.detach()) < 1e-3
+    p64 = dict(o64.named_parameters())
+    n0 = net.first_bn_channels
+    worst = (0.0, None)
+    for lname, L in net._layers.items():
+        nw = L["cout"] * L["k"] * L["k"] * L["cin"]
+        gw = net.flat_weight.grad[L["w_off"]:L["w_off"] + nw].view(L["cout"], L["k"], L["k"], L["cin"]).permute(0, 3, 1, 2)
+        a, b_ = L["c_off"], L["c_off"] + L["cout"]
+        gg = net.bn_weight_first.grad[a:b_] if b_ <= n0 else net.bn_weight_rest.grad[a - n0:b_ - n0]
+        gb = net.bn_bias_first.grad[a:b_] if b_ <= n0 else net.bn_bias_rest.grad[a - n0:b_ - n0]
+        for got, key in ((gw, lname + ".weight"), (gg, lname + "_bn.weight"), (gb, lname + "_bn.bias")):
+            e = l2_err(got, p64[key].grad)
+            if e > worst[0]:
+                worst = (e, key)
+            assert e < 5e-4, (key, e)         # the north star asks 1e-3; observed worst over all five cases: 1.05e-4
+    print(f"forced-decision gradient case {cin_hw}: worst relative L2 error {worst[0]:.2e} at {worst[1]}")
+
+
 def test_full_size_properties_config4_shapes():
     """BASELINE.json full input sizes (3x224x224 RGB, 10x224x224 flow, 256x256 spectrogram):
     eval logits of a clip do not depend on its batch neighbours, equal-segment clips reproduce
