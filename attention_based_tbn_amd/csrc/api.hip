@@ -47,12 +47,12 @@ static void conv_geom(ConvP* p, int n, int h, int w, int cin, int cout, int k, i
 namespace {
 struct ProfRec {
   int name;
-  double flops;
+  double flops, bytes;
   hipEvent_t a, b;
 };
 struct ProfAgg {
   long launches = 0;
-  double ms = 0, flops = 0;
+  double ms = 0, flops = 0, bytes = 0;
 };
 std::mutex g_prof_mu;
 bool g_prof_on = false;
@@ -84,6 +84,7 @@ void prof_collect() {
     a.launches += 1;
     a.ms += ms;
     a.flops += r.flops;
+    a.bytes += r.bytes;
     g_prof_pool.push_back(r.a);
     g_prof_pool.push_back(r.b);
   }
@@ -93,7 +94,7 @@ void prof_collect() {
 }
 }  // namespace
 
-void tbn_prof_begin(const char* kernel, double flops, hipStream_t st) {
+void tbn_prof_begin(const char* kernel, double flops, hipStream_t st, double bytes) {
   if (!g_prof_on) return;
   std::lock_guard<std::mutex> lk(g_prof_mu);
   std::string key = kernel;
@@ -109,6 +110,7 @@ void tbn_prof_begin(const char* kernel, double flops, hipStream_t st) {
   ProfRec r;
   r.name = idx;
   r.flops = flops;
+  r.bytes = bytes;
   r.a = prof_event();
   r.b = prof_event();
   (void)hipEventRecord(r.a, st);
@@ -157,6 +159,12 @@ int tbn_profile_entry(int i, char* name, int name_len, long* launches, double* t
   if (launches) *launches = a.launches;
   if (total_ms) *total_ms = a.ms;
   if (total_flops) *total_flops = a.flops;
+  return TBN_OK;
+}
+int tbn_profile_entry_bytes(int i, double* total_alg_bytes) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  TBN_REQUIRE(i >= 0 && i < (int)g_prof_keys.size() && total_alg_bytes, "profile_entry_bytes: bad index");
+  *total_alg_bytes = g_prof_agg[g_prof_keys[i]].bytes;
   return TBN_OK;
 }
 const char* tbn_last_error(void) { return g_err; }

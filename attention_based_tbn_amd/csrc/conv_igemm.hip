@@ -954,6 +954,16 @@ int tbn_conv_red_rows(int N, int OH, int OW, int up, int mt) {
   return rows;
 }
 
+// algorithmic HBM bytes of one conv launch: the input read once, the weights once, the output written once (read
+// once more when accumulating; + the BN input read by a fused backward reduce)
+static double conv_alg_bytes(const ConvP& p, int rowmode) {
+  const double in = (double)p.N * p.H * p.W * (rowmode ? p.cp : p.Cin);
+  double out = (double)p.M * p.Cout;
+  if (p.flags & CONV_FLAG_ACCUM) out *= 2.0;
+  if (p.nred > 0) out += (double)p.M * p.Cout;
+  return 4.0 * (in + (double)p.Cout * p.Krow + out);
+}
+
 static int launch_conv_tiles(ConvP& p, int rowmode, int mt, int nt, hipStream_t st) {
   if (mt <= 0 || nt <= 0) tbn_conv_pick_tile(p.M, p.Cout, p.K, &mt, &nt);
   if (p.stages != 1 && p.stages != 2) p.stages = (mt == 1) ? 2 : 1;  // big tiles: keep 2 workgroups per CU
@@ -966,7 +976,7 @@ static int launch_conv_tiles(ConvP& p, int rowmode, int mt, int nt, hipStream_t 
     char nm[64];
     const int epi = p.mode == CONV_EPI_STATS ? 1 : (p.mode == CONV_EPI_EVAL ? 2 : 0);
     snprintf(nm, sizeof(nm), "conv_halo_kernel<%d, %d, %d%s>", mt, nt, epi, (p.nred > 0 && epi == 0) ? ", true" : "");
-    tbn_prof_begin(nm, p.alg_flops, st);
+    tbn_prof_begin(nm, p.alg_flops, st, conv_alg_bytes(p, rowmode));
     int rc = TBN_OK;
 #define TBN_HCASE(MTv, NTv) \
   if (mt == MTv && nt == NTv) rc = launch_halo<MTv, NTv>(p, lds_bytes, st);
@@ -982,7 +992,7 @@ static int launch_conv_tiles(ConvP& p, int rowmode, int mt, int nt, hipStream_t 
     const int epi = p.mode == CONV_EPI_STATS ? 1 : (p.mode == CONV_EPI_EVAL ? 2 : ((p.out_sy != 1 || p.out_sx != 1) ? 3 : 0));
     snprintf(nm, sizeof(nm), "conv_igemm_kernel<%d, %d, %s, %d, %d%s>", mt, nt, rowmode ? "true" : "false", epi, p.stages,
              (p.nred > 0 && epi == 0 && !rowmode) ? ", true" : "");
-    tbn_prof_begin(nm, p.alg_flops, st);
+    tbn_prof_begin(nm, p.alg_flops, st, conv_alg_bytes(p, rowmode));
   }
 #define TBN_CASE(MTv, NTv)                                     \
   if (mt == MTv && nt == NTv) {                                \
@@ -1147,7 +1157,7 @@ int tbn_launch_conv(ConvP p, int rowmode, int mt, int nt, hipStream_t st) {
   {
     char nm[64];
     snprintf(nm, sizeof(nm), "conv_igemm_phases_kernel<%d, %d, %d%s>", pmt, pnt, stages, p.nred > 0 ? ", true" : "");
-    tbn_prof_begin(nm, flops_total, st);
+    tbn_prof_begin(nm, flops_total, st, conv_alg_bytes(p, 0));
   }
 #define TBN_PLAUNCH(MTv, NTv, STv, REDv) \
   hipLaunchKernelGGL((conv_igemm_phases_kernel<MTv, NTv, STv, REDv>), dim3(phases.blk0[phases.n]), dim3(256), 0, st, phases)
@@ -1276,7 +1286,9 @@ int tbn_launch_wgrad(WgradP p, int rowmode, float* dw, float* workspace, hipStre
   {
     char nm[64];
     snprintf(nm, sizeof(nm), "conv_wgrad_kernel<%d, %d, %s>", mt, nt, rowmode ? "true" : "false");
-    tbn_prof_begin(nm, p.alg_flops, st);
+    // algorithmic bytes: dy and x read once, dW written once (split-K slabs are overhead, not counted)
+    tbn_prof_begin(nm, p.alg_flops, st,
+                   4.0 * ((double)p.M * p.Cout + (double)p.N * p.H * p.W * (rowmode ? p.cp : p.Cin) + (double)p.Cout * p.K));
   }
 #define TBN_CASE(MTv, NTv)                                          \
   if (mt == MTv && nt == NTv) {                                     \

@@ -135,8 +135,11 @@ struct tbn_backbone_plan {
   size_t partial_floats, wsplit_floats, wt_floats;
   size_t argmax_bytes_off, total_bytes_train, total_bytes_eval;
   size_t eval_floats;
-  // fork/join events for the optional aux (weight-gradient) stream; created on first use
-  hipEvent_t ev[8];
+  // fork/join events for the optional aux (weight-gradient) stream; created on first use.  One event per fork (a
+  // backward pass never records an event twice: re-recording inside a stream capture is where ROCm 7.2 fell over)
+  // + one for the join.
+  static const int kEvents = 72;
+  hipEvent_t ev[kEvents];
   int n_ev = 0;
 };
 
@@ -1095,8 +1098,9 @@ int tbn_backbone_backward(const tbn_backbone_plan* P, const float* dfeatures, co
   hipStream_t aux = (hipStream_t)g->aux_stream;
   tbn_backbone_plan* PM = const_cast<tbn_backbone_plan*>(P);  // event pool only
   if (aux == st) aux = nullptr;
+  constexpr int NE = tbn_backbone_plan::kEvents;
   if (aux != nullptr && PM->n_ev == 0) {
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < NE; ++i) {
       if (hipEventCreateWithFlags(&PM->ev[i], hipEventDisableTiming) != hipSuccess) {
         tbn_set_error("backbone_backward: hipEventCreate failed");
         return TBN_ERR_LAUNCH;
@@ -1104,10 +1108,10 @@ int tbn_backbone_backward(const tbn_backbone_plan* P, const float* dfeatures, co
       PM->n_ev = i + 1;
     }
   }
-  TBN_REQUIRE(aux == nullptr || PM->n_ev == 8, "backbone_backward: event pool incomplete");
-  // events 0..6 fork (launch stream -> aux), event 7 is the join: whatever path leaves this function, the aux stream
-  // is joined back (a fork left open would also break hipGraph capture of a step)
-  AuxJoin join{st, aux, aux != nullptr ? PM->ev[7] : nullptr};
+  TBN_REQUIRE(aux == nullptr || (PM->n_ev == NE && (int)P->convs.size() < NE), "backbone_backward: event pool too small");
+  // events 0..NE-2 fork (launch stream -> aux), the last one is the join: whatever path leaves this function, the aux
+  // stream is joined back (a fork left open would also break hipGraph capture of a step)
+  AuxJoin join{st, aux, aux != nullptr ? PM->ev[NE - 1] : nullptr};
   int ev_next = 0;
   float* ws = (float*)workspace;
   const int R = P->frames;
@@ -1218,8 +1222,7 @@ int tbn_backbone_backward(const tbn_backbone_plan* P, const float* dfeatures, co
     tbn_prof_label(("wgrad " + c.parts[c.nparts - 1].name).c_str());
     hipStream_t wst = st;
     if (aux != nullptr) {
-      hipEvent_t e = PM->ev[ev_next];
-      ev_next = (ev_next + 1) % 7;
+      hipEvent_t e = PM->ev[ev_next++];
       (void)hipEventRecord(e, st);
       (void)hipStreamWaitEvent(aux, e, 0);
       join.forked = true;

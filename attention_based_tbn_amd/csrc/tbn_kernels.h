@@ -84,7 +84,7 @@ struct WgradP {
 };
 
 // optional in-process profiler: brackets every conv-GEMM launch with hipEvents on its stream
-void tbn_prof_begin(const char* kernel, double flops, hipStream_t st);
+void tbn_prof_begin(const char* kernel, double flops, hipStream_t st, double alg_bytes = 0.0);
 void tbn_prof_end(hipStream_t st);
 void tbn_prof_label(const char* label);
 

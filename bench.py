@@ -64,15 +64,19 @@ def collect_profile():
     out = []
     name = C.create_string_buffer(96)
     for i in range(L.tbn_profile_num_entries()):
-        n, ms, fl = C.c_long(), C.c_double(), C.c_double()
+        n, ms, fl, by = C.c_long(), C.c_double(), C.c_double(), C.c_double()
         L.tbn_profile_entry(i, name, 96, C.byref(n), C.byref(ms), C.byref(fl))
-        out.append({"kernel": name.value.decode(), "launches": n.value, "ms": ms.value, "flops": fl.value})
+        L.tbn_profile_entry_bytes(i, C.byref(by))
+        out.append({"kernel": name.value.decode(), "launches": n.value, "ms": ms.value, "flops": fl.value,
+                    "alg_bytes": by.value})
     return out
 
 
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the newest committed PMC summary (separate rocprofv3 --pmc
-    FETCH_SIZE / WRITE_SIZE passes of this same command, scripts/pmc_traffic.py); None if there is none."""
+    FETCH_SIZE / WRITE_SIZE passes of this same command with the priming / autotune / warm-up steps filtered out,
+    scripts/pmc_traffic.py); None if there is none.  PMC counters cannot be read from inside the process: the figure
+    is the one collected from the commit named in the file's `note`."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
     if not files:
@@ -258,6 +262,8 @@ def main():
         opt.step(clip_grad=cfg.train.clip_grad)   # clip_grad_norm_(20) + SGD(momentum) in three HIP launches
         return loss["total"].detach()      # no reference to the autograd graph survives the step
 
+    if world > 1 and hasattr(model, "time_sync"):
+        model.time_sync = True     # HIP events around finish_gradient_sync: the all-reduce tail backward did not hide
     multi = not args.no_multi_stream
     core.multi_stream = multi
     aux = [b_.use_aux_stream and not args.no_aux_stream for b_ in bases]   # the model's own policy unless switched off
@@ -277,6 +283,8 @@ def main():
     L = lib()
     L.tbn_profile_reset()
     fence()
+    if world > 1 and hasattr(model, "exposed_sync_ms"):
+        model.exposed_sync_ms()     # drop the warm-up records
     t0 = time.perf_counter()
     for i in range(args.steps):
         prof = args.profile_every > 0 and (i % args.profile_every == 0)
@@ -300,6 +308,12 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     assert os.environ.get("TBN_DIAG_SKIP") or torch.isfinite(loss).item(), "loss is not finite"
+    exposed_ms = None
+    if world > 1 and hasattr(model, "exposed_sync_ms"):
+        e = model.exposed_sync_ms()
+        t = torch.tensor([e if e is not None else 0.0], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        exposed_ms = float(t.item())
 
     if rank == 0:
         clips = B * world * args.steps
@@ -310,9 +324,13 @@ def main():
             top = prof[0]
             ach = top["flops"] / (top["ms"] * 1e-3) / 1e12
             tot_ms, tot_fl = sum(e["ms"] for e in prof), sum(e["flops"] for e in prof)
+            tr = pmc_traffic(top["kernel"])
+            alg_b = top["alg_bytes"] / max(1, top["launches"])
             roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": (pmc_traffic(top["kernel"]) or {}).get("hbm_bytes_per_launch"),
-                        "traffic_detail": pmc_traffic(top["kernel"]),
+                        "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": (tr or {}).get("hbm_bytes_per_launch"),
+                        "alg_bytes_per_launch": round(alg_b),
+                        "traffic_ratio": round(tr["hbm_bytes_per_launch"] / alg_b, 3) if tr and alg_b > 0 else None,
+                        "traffic_detail": tr,
                         "kernel": top["kernel"], "launches": top["launches"],
                         "avg_launch_us": round(1e3 * top["ms"] / top["launches"], 2),
                         "alg_gflop_per_launch": round(top["flops"] / top["launches"] / 1e9, 4),
@@ -336,6 +354,10 @@ def main():
                        **({"audio_input": "waveform (30695 samples), STFT kernel inside the timed step"} if args.stft_inputs else {})},
             "roofline": roofline,
         }
+        if exposed_ms is not None:
+            # mean GPU time per step between the end of the last backbone's backward (entry of the gradient-sync
+            # callback on the compute stream) and the return of finish_gradient_sync, max over ranks
+            line["exposed_allreduce_ms"] = round(exposed_ms, 3)
         if world == 1 and not args.no_cpu_baseline and args.config == 4 and not args.forward_only:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), file=json_out, flush=True)

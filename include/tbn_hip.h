@@ -40,6 +40,9 @@ int tbn_profile_enable(int on);
 int tbn_profile_reset(void);
 int tbn_profile_num_entries(void);
 int tbn_profile_entry(int i, char* name, int name_len, long* launches, double* total_ms, double* total_flops);
+/* summed ALGORITHMIC HBM bytes of entry i: per launch the input read once + weights once + output written once (conv /
+ * data gradient), dy + x read once + dW written once (weight gradient) -- the denominator of the traffic ratio */
+int tbn_profile_entry_bytes(int i, double* total_alg_bytes);
 
 /* ---- BN-Inception backbone engine -------------------------------------------------------------
  * replaces: BNInception.features() as instantiated by reference core/models/bn_inception.py:38-107

@@ -4,8 +4,11 @@ MI355X_MICROARCH.md HBM section) of `bench.py --profile-every 1` into HBM bytes 
 kernel.  FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 128-B requests as 64 B for
 wide coalesced reads, so the read side is doubled (upper bound for narrow reads).
 
+Only the TIMED steps count: a step ends with one `opt_sgd_kernel` dispatch, so everything up to the SKIP-th such
+dispatch (priming step with the per-layer tile autotune + warm-up steps) is dropped.
+
   python scripts/pmc_traffic.py gpurun_out/pmc_fetch/fetch_counter_collection.csv \
-         gpurun_out/pmc_write/write_counter_collection.csv profiles/r01_pmc_traffic.json
+         gpurun_out/pmc_write/write_counter_collection.csv profiles/r02_pmc_traffic.json [SKIP=3] [note]
 """
 import csv
 import json
@@ -20,20 +23,30 @@ def short(name):
     return name.replace("(anonymous namespace)::", "")
 
 
-def load(path, counter):
+def load(path, counter, skip_steps):
     acc = defaultdict(lambda: [0, 0.0])
     with open(path) as f:
-        for row in csv.DictReader(f):
-            if row["Counter_Name"] != counter:
-                continue
-            k = short(row["Kernel_Name"])
-            acc[k][0] += 1
-            acc[k][1] += float(row["Counter_Value"])
+        rows = [r for r in csv.DictReader(f) if r["Counter_Name"] == counter]
+    rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+    steps_seen, first = 0, 0
+    for r in rows:
+        if steps_seen >= skip_steps:
+            break
+        first = int(r["Dispatch_Id"])
+        if "opt_sgd_kernel" in r["Kernel_Name"]:
+            steps_seen += 1
+    for row in rows:
+        if skip_steps and int(row["Dispatch_Id"]) <= first:
+            continue
+        k = short(row["Kernel_Name"])
+        acc[k][0] += 1
+        acc[k][1] += float(row["Counter_Value"])
     return acc
 
 
 def main():
-    fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
+    skip = int(sys.argv[4]) if len(sys.argv) > 4 else 3
+    fetch, write = load(sys.argv[1], "FETCH_SIZE", skip), load(sys.argv[2], "WRITE_SIZE", skip)
     out = {}
     for k in sorted(set(fetch) | set(write)):
         nf, f = fetch.get(k, [0, 0.0])
@@ -47,7 +60,9 @@ def main():
                   "hbm_bytes_per_launch": round(rd + wr)}
     tot = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in out.values())
     res = {"note": "FETCH_SIZE x2 gfx950 correction applied to reads; separate --pmc passes; bytes per launch averaged over "
-                   "all launches of that kernel name in bench.py --steps 3 --warmup 2 --profile-every 1 (B=32)",
+                   "the launches of that kernel name in the TIMED steps of bench.py --steps 3 --warmup 2 --profile-every 1 "
+                   f"(B=32; the first {skip} steps -- priming with autotune + warm-up -- are filtered out)"
+                   + (" | " + sys.argv[5] if len(sys.argv) > 5 else ""),
            "total_hbm_bytes_all_launches": tot, "kernels": out}
     with open(sys.argv[3], "w") as f:
         json.dump(res, f, indent=1)
