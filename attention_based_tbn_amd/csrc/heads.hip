@@ -125,13 +125,34 @@ __global__ __launch_bounds__(256) void groupnorm_bwd_kernel(const float* __restr
 }
 
 // out[c] = sum_rows x[row][c]  (fixed order -> deterministic)
+// Column sums (bias gradient of a linear layer).  One workgroup per 32 columns: 8 row lanes x 32 column lanes, a row
+// lane walks rows y, y + 8, ... with four independent partial sums (the former one-thread-per-column loop was a
+// 1536-long dependent chain: 94 us on the PE / in_proj matrices of config 3), then a fixed-order LDS reduction.
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, int x_ld, float* __restrict__ out,
                                                      int rows, int cols) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= cols) return;
-  float s = 0.f;
-  for (int r = 0; r < rows; ++r) s += x[(size_t)r * x_ld + c];
-  out[c] = s;
+  __shared__ float red[8][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + tx;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (c < cols) {
+    const float* p = x + c;
+    int r = ty;
+    for (; r + 24 < rows; r += 32) {
+      s0 += p[(size_t)r * x_ld];
+      s1 += p[(size_t)(r + 8) * x_ld];
+      s2 += p[(size_t)(r + 16) * x_ld];
+      s3 += p[(size_t)(r + 24) * x_ld];
+    }
+    for (; r < rows; r += 8) s0 += p[(size_t)r * x_ld];
+  }
+  red[ty][tx] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (ty == 0 && c < cols) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += red[k][tx];
+    out[c] = s;
+  }
 }
 
 // ---------------------------------------------------------------- MHA core, L_q = 1
@@ -367,7 +388,7 @@ int tbn_groupnorm_bwd(const float* dy, const float* x, const float* gamma, const
 }
 
 int tbn_colsum(const float* x, int x_ld, float* out, int rows, int cols, void* stream) {
-  hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(cols, 256)), dim3(256), 0, (hipStream_t)stream, x, x_ld, out, rows, cols);
+  hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(cols, 32)), dim3(256), 0, (hipStream_t)stream, x, x_ld, out, rows, cols);
   TBN_CHECK_LAUNCH("colsum");
   return TBN_OK;
 }

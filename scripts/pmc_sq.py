@@ -15,7 +15,7 @@ for r in rows:
                             "t": int(r["End_Timestamp"]) - int(r["Start_Timestamp"])})
     e[r["Counter_Name"]] = float(r["Counter_Value"])
 ids = list(disp)
-start = max(i for i in ids if disp[i]["k"].startswith("nchw_to_nhwc_pad"))
+start = max(i for i in ids if disp[i]["k"].startswith(("nchw_to_nhwc_pad", "nchw1_to_s2d")))
 agg = defaultdict(lambda: defaultdict(float))
 for i in ids:
     if i < start: continue
