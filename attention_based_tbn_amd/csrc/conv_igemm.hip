@@ -608,6 +608,196 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(ConvP p) {
   conv_halo_body<MT, NT, EPI, RED>(p, blockIdx.x, dyn_lds);
 }
 
+// ------------------------------------------------------------------------------------------
+// LDS-DMA variant of the generic implicit GEMM (1x1 / 3x3, any stride; not the stem): the A and B tiles go from
+// global memory STRAIGHT into LDS (`buffer_load_dwordx4 ... lds`: no VGPR round trip, no ds_write issue, 4*MT + NT
+// fewer VGPR quads), two stages, one barrier per K-step.  An LDS-DMA instruction writes lane l's 16 bytes at
+// (wave-uniform base) + 16 l, i.e. 8 rows x 128 B per wave instruction: rows are UNPADDED and conflict-free b128
+// fragment reads come from an XOR swizzle instead -- 16-B slot q of tile row r lives at slot q ^ ((r >> 1) & 7); the
+// swizzle is applied on the global SOURCE address of each lane (lane (row l >> 3, slot l & 7) fetches chunk
+// (l & 7) ^ f(row)) and again on the fragment read.  Out-of-image taps / rows beyond M or Cout are out-of-range buffer
+// offsets: the DMA writes zeros.
+// The DMA is issued through inline asm: hipcc would otherwise treat each LDS-DMA as a pending LDS write and put an
+// `s_waitcnt vmcnt(0)` in front of the next fragment read -- draining the prefetch it is supposed to overlap.  The
+// asm statement is invisible to that bookkeeping; the wait is placed by hand before the barrier that publishes the
+// stage (cdna_hip_programming.md 5.7: M0 is written in the same statement that uses it).
+__device__ __forceinline__ void lds_dma16(i32x4 rsrc, unsigned lds_dst, unsigned voff, unsigned soff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+               :
+               : "s"(lds_dst), "v"(voff), "s"(rsrc), "s"(soff)
+               : "memory");
+}
+
+template <int MT, int NT, int EPI, bool RED>
+__device__ __forceinline__ void conv_dma_body(const ConvP& p, const int bid, float* lds) {
+  constexpr int BM = 128 * MT, BN = 32 * NT;
+  constexpr int AR = 4 * MT;                 // 8-row DMA instructions per wave for the A tile
+  constexpr int TILE_B = (BM + BN) * 128;    // bytes per LDS stage (A rows then B rows, 128 B each)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nb = p.tiles_m * p.tiles_n;
+  const int q8 = nb >> 3, r8 = nb & 7, xcd = bid & 7, idx = bid >> 3;
+  const int nid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+  const int tm = nid / p.tiles_n, tn = nid - tm * p.tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const i32x4 in_rsrc = make_rsrc(p.in, p.in_bytes);
+  const i32x4 wt_rsrc = make_rsrc(p.wt, p.wt_bytes);
+
+  const int rl = lane >> 3, slot = lane & 7;   // row within the 8-row group / 16-B slot this lane's bytes land in
+  unsigned a_off[AR], a_mask[AR];
+#pragma unroll
+  for (int i = 0; i < AR; ++i) {
+    const int r = (wave * AR + i) * 8 + rl;    // tile row
+    const int m = m0 + r;
+    unsigned mask = 0;
+    int off = 0;
+    if (m < p.M) {
+      const uint32_t n = fdiv((uint32_t)m, p.div_ohw);
+      const uint32_t rem = (uint32_t)m - n * p.div_ohw.d;
+      const uint32_t a = fdiv(rem, p.div_ow);
+      const uint32_t b = rem - a * p.div_ow.d;
+      const int iy0 = (int)a * p.in_sy, ix0 = (int)b * p.in_sx;
+      unsigned yb = 0, xb = 0;
+#pragma unroll
+      for (int rr = 0; rr < 3; ++rr)
+        if (rr < p.tny && (unsigned)(iy0 + p.ty0 + rr) < (unsigned)p.H) yb |= 1u << rr;
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        if (c < p.tnx && (unsigned)(ix0 + p.tx0 + c) < (unsigned)p.W) xb |= 1u << c;
+#pragma unroll
+      for (int rr = 0; rr < 3; ++rr)
+        if ((yb >> rr) & 1u) mask |= xb << (rr * p.tnx);
+      off = (((int)n * p.H + iy0) * p.W + ix0) * p.in_ld * 4 + ((slot ^ ((r >> 1) & 7)) << 4);   // swizzled source chunk
+    }
+    a_off[i] = (unsigned)off;
+    a_mask[i] = mask;
+  }
+  unsigned b_voff[NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i) {
+    const int r = (wave + 4 * i) * 8 + rl;     // B tile row (= output channel n0 + r); rows >= Cout: beyond wt_bytes
+    b_voff[i] = (unsigned)(n0 + r) * (unsigned)p.Krow * 4u + (unsigned)((slot ^ ((r >> 1) & 7)) << 4);
+  }
+  // wave-uniform LDS byte addresses of this wave's DMA instructions (stage 0)
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
+  char* const lds_b = reinterpret_cast<char*>(lds);
+  // (the low 32 bits of a generic pointer into LDS are the LDS byte offset)
+  const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)lds_b);
+
+  int l_tap = 0, l_c0 = 0;
+  unsigned l_toff = (unsigned)p.tap_off[0], l_koff = (unsigned)p.tap_koff[0] * 4u;
+  unsigned a_cur[AR];
+  auto issue_tiles = [&](int stage) {
+    if (l_c0 == 0) {
+#pragma unroll
+      for (int i = 0; i < AR; ++i) a_cur[i] = ((a_mask[i] >> l_tap) & 1u) ? a_off[i] + l_toff : TBN_OOB;
+    }
+    const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(l_c0 * 4);
+    const unsigned st = lds0 + (unsigned)(stage * TILE_B);
+#pragma unroll
+    for (int i = 0; i < AR; ++i) lds_dma16(in_rsrc, st + (unsigned)((wv * AR + i) * 1024), a_cur[i], soff);
+    const unsigned koff = (unsigned)__builtin_amdgcn_readfirstlane((int)l_koff + l_c0 * 4);
+#pragma unroll
+    for (int i = 0; i < NT; ++i) lds_dma16(wt_rsrc, st + (unsigned)(BM * 128 + (wv + 4 * i) * 1024), b_voff[i], koff);
+    l_c0 += 32;
+    if (l_c0 == p.Cin) {
+      l_c0 = 0;
+      ++l_tap;
+      if (l_tap < p.ntaps) {
+        l_toff = (unsigned)p.tap_off[l_tap];
+        l_koff = (unsigned)p.tap_koff[l_tap] * 4u;
+      }
+    }
+  };
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // fragment addresses (bytes, stage 0): logical 16-B chunk (2 kg + lhalf) of row r sits at slot chunk ^ f(r)
+  const int lrow = lane & 31, lhalf = lane >> 5;
+  unsigned fa_addr[MT][4], fb_addr[NT][4];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int r = wave * 32 * MT + i * 32 + lrow;
+#pragma unroll
+    for (int kg = 0; kg < 4; ++kg) fa_addr[i][kg] = (unsigned)(r * 128 + (((2 * kg + lhalf) ^ ((r >> 1) & 7)) << 4));
+  }
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int r = j * 32 + lrow;
+#pragma unroll
+    for (int kg = 0; kg < 4; ++kg)
+      fb_addr[j][kg] = (unsigned)(BM * 128 + r * 128 + (((2 * kg + lhalf) ^ ((r >> 1) & 7)) << 4));
+  }
+
+  const int ksteps = p.K >> 5;
+  issue_tiles(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();   // publishes stage 0
+
+  auto compute = [&](const char* sb) {
+    float4 fa[2][MT], fb[2][NT];
+    auto frag_load = [&](int buf, int kg) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i) fa[buf][i] = *reinterpret_cast<const float4*>(sb + fa_addr[i][kg]);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) fb[buf][j] = *reinterpret_cast<const float4*>(sb + fb_addr[j][kg]);
+    };
+    auto mfma_group = [&](int buf) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[buf][i].x, fb[buf][j].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[buf][i].y, fb[buf][j].y, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[buf][i].z, fb[buf][j].z, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[buf][i].w, fb[buf][j].w, acc[i][j], 0, 0, 0);
+        }
+    };
+    frag_load(0, 0);
+    frag_load(1, 1);
+    mfma_group(0);
+    frag_load(0, 2);
+    mfma_group(1);
+    frag_load(1, 3);
+    mfma_group(0);
+    mfma_group(1);
+    {
+      constexpr int NR = MT + NT, NM = 4 * MT * NT;
+      __builtin_amdgcn_sched_group_barrier(0x100, 2 * NR, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, NR, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, NR, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 2 * NM, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  // two K-steps per iteration: the stage is a compile-time constant (fragment offsets stay immediates)
+  for (int ks = 0; ks < ksteps; ks += 2) {
+    if (ks + 1 < ksteps) issue_tiles(1);     // stage 1 was last read in step ks - 1: every wave is past that barrier
+    compute(lds_b);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA of the next stage has landed ...
+    __syncthreads();                                    // ... and so has everyone else's
+    if (ks + 1 >= ksteps) break;
+    if (ks + 2 < ksteps) issue_tiles(0);
+    compute(lds_b + TILE_B);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  conv_epilogue<MT, NT, EPI, RED>(p, acc, lds, tm, m0, n0);
+}
+
+template <int MT, int NT, int EPI, bool RED>
+__global__ __launch_bounds__(256) void conv_dma_kernel(ConvP p) {
+  __shared__ __attribute__((aligned(1024))) float lds[2 * (128 * MT + 32 * NT) * 32];
+  conv_dma_body<MT, NT, EPI, RED>(p, blockIdx.x, lds);
+}
+
 // The four output-parity phases of a stride-2 data gradient in ONE launch: each phase alone is a small GEMM
 // (M / 4 rows, 1-4 taps) that leaves most CUs idle; a workgroup finds its phase by a scalar scan.
 struct ConvPhases {
@@ -918,6 +1108,19 @@ static int launch_halo(const ConvP& p, size_t lds_bytes, hipStream_t st) {
   return launch_halo_e<MT, NT, 0, false>(p, lds_bytes, st);
 }
 
+template <int MT, int NT>
+static void launch_dma(const ConvP& p, hipStream_t st) {
+  const dim3 grid(p.tiles_m * p.tiles_n);
+  if (p.mode == CONV_EPI_STATS)
+    hipLaunchKernelGGL((conv_dma_kernel<MT, NT, 1, false>), grid, dim3(256), 0, st, p);
+  else if (p.mode == CONV_EPI_EVAL)
+    hipLaunchKernelGGL((conv_dma_kernel<MT, NT, 2, false>), grid, dim3(256), 0, st, p);
+  else if (p.nred > 0)
+    hipLaunchKernelGGL((conv_dma_kernel<MT, NT, 0, true>), grid, dim3(256), 0, st, p);
+  else
+    hipLaunchKernelGGL((conv_dma_kernel<MT, NT, 0, false>), grid, dim3(256), 0, st, p);
+}
+
 void tbn_conv_pick_tile(int M, int Cout, int K, int* mt_out, int* nt_out) {
   double best = 1e300;
   int bm = 1, bn = 1;
@@ -969,7 +1172,22 @@ static int launch_conv_tiles(ConvP& p, int rowmode, int mt, int nt, hipStream_t 
   if (p.stages != 1 && p.stages != 2) p.stages = (mt == 1) ? 2 : 1;  // big tiles: keep 2 workgroups per CU
   p.tiles_m = cdiv(p.M, 128 * mt);
   p.tiles_n = cdiv(p.Cout, 32 * nt);
-  if (p.halo && !rowmode) {
+  if (p.halo == 2 && !rowmode) {   // LDS-DMA staging
+    const bool scatter = (p.out_sy != 1) || (p.out_sx != 1);
+    TBN_REQUIRE(!scatter && mt <= 2 && nt <= 4, "conv: the LDS-DMA kernel does not handle this launch");
+    char nm[64];
+    const int epi = p.mode == CONV_EPI_STATS ? 1 : (p.mode == CONV_EPI_EVAL ? 2 : 0);
+    snprintf(nm, sizeof(nm), "conv_dma_kernel<%d, %d, %d%s>", mt, nt, epi, (p.nred > 0 && epi == 0) ? ", true" : "");
+    tbn_prof_begin(nm, p.alg_flops, st, conv_alg_bytes(p, rowmode));
+#define TBN_DCASE(MTv, NTv) \
+  if (mt == MTv && nt == NTv) launch_dma<MTv, NTv>(p, st);
+    TBN_DCASE(1, 1) TBN_DCASE(1, 2) TBN_DCASE(1, 3) TBN_DCASE(1, 4) TBN_DCASE(2, 1) TBN_DCASE(2, 2) TBN_DCASE(2, 3) TBN_DCASE(2, 4)
+#undef TBN_DCASE
+    tbn_prof_end(st);
+    TBN_CHECK_LAUNCH("conv_dma");
+    return TBN_OK;
+  }
+  if (p.halo == 1 && !rowmode) {
     const size_t lds_bytes = tbn_conv_halo_lds_bytes(p, mt, nt);
     TBN_REQUIRE(lds_bytes > 0 && lds_bytes <= 160 * 1024, "conv: the LDS-halo kernel does not handle this shape / tile");
     TBN_REQUIRE(mt <= 2 && nt <= 4, "conv: unsupported halo tile %dx%d", mt, nt);
@@ -1035,6 +1253,7 @@ int tbn_launch_conv(ConvP p, int rowmode, int mt, int nt, hipStream_t st) {
   }
   TBN_REQUIRE(p.up == 1 || p.up == 2, "conv: up must be 1 or 2");
   if (p.flags & CONV_FLAG_HALO) p.halo = 1;
+  if (p.flags & CONV_FLAG_DMA) p.halo = 2;
   TBN_REQUIRE(p.M > 0, "conv: empty problem");
   const size_t in_bytes = (size_t)p.N * p.H * p.W * (rowmode ? p.cp : p.in_ld) * sizeof(float);
   TBN_REQUIRE(in_bytes < (1ull << 31), "conv: input extent %zu B >= 2 GiB (process the frames in chunks)", in_bytes);

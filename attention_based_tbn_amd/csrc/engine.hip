@@ -1044,17 +1044,20 @@ int tbn_backbone_autotune(tbn_backbone_plan* P, int training, const tbn_backbone
       static const int force_halo = getenv("TBN_FORCE_HALO") ? atoi(getenv("TBN_FORCE_HALO")) : -1;   // tests: 0 / 1
       for (int mt = 1; mt <= 2 && rc == TBN_OK; ++mt)
         for (int nt = 1; nt <= 4 && rc == TBN_OK; ++nt)
-          for (int stg = 0; stg <= 2 && rc == TBN_OK; ++stg) {   // 0: the LDS-halo kernel (3x3 / stride-1 layers)
+          for (int stg = 0; stg <= 3 && rc == TBN_OK; ++stg) {   // 0: LDS-halo kernel (3x3 / stride-1 layers), 3: LDS-DMA
             if (32 * (nt - 1) >= p.Cout) continue;
-            p.halo = stg == 0;
-            if (p.halo) {
+            static const int use_dma = getenv("TBN_USE_DMA") ? atoi(getenv("TBN_USE_DMA")) : 1;
+            p.halo = stg == 0 ? 1 : (stg == 3 ? 2 : 0);
+            if (stg == 3) {
+              if ((c.stem && pass == 0) || p.up != 1 || !use_dma || force_halo == 1) continue;
+            } else if (p.halo) {
               const size_t lb = (c.stem && pass == 0) ? 0 : tbn_conv_halo_lds_bytes(p, mt, nt);
               if (lb == 0 || lb > 160 * 1024 || force_halo == 0) continue;
             } else if (force_halo == 1 && !(c.stem && pass == 0) && tbn_conv_halo_lds_bytes(p, 1, 1) > 0) {
               continue;
             }
             float ms = 0.f;
-            p.stages = stg;
+            p.stages = stg == 3 ? 2 : stg;
             for (int rep = 0; rep < 2 && rc == TBN_OK; ++rep) {
               (void)hipEventRecord(e0, st);
               rc = tbn_launch_conv(p, c.stem && pass == 0, mt, nt, st);
@@ -1066,7 +1069,7 @@ int tbn_backbone_autotune(tbn_backbone_plan* P, int training, const tbn_backbone
               best = ms;
               bm = mt;
               bn = nt;
-              bs = stg;
+              bs = p.stages;
               bh = p.halo;
             }
           }

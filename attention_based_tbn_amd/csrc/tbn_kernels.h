@@ -3,7 +3,12 @@
 #include "tbn_common.h"
 
 enum { CONV_EPI_PLAIN = 0, CONV_EPI_STATS = 1, CONV_EPI_EVAL = 2 };
-enum { CONV_FLAG_ACCUM = 1, CONV_FLAG_RELU = 2, CONV_FLAG_HALO = 4 /* host only: use the LDS-halo kernel */ };
+enum {
+  CONV_FLAG_ACCUM = 1,
+  CONV_FLAG_RELU = 2,
+  CONV_FLAG_HALO = 4,   // host only: use the LDS-halo kernel
+  CONV_FLAG_DMA = 8     // host only: use the LDS-DMA staging kernel
+};
 
 // BN-backward reduce fused into a data-gradient epilogue (the launch that writes the FINAL value of dz): for the output
 // columns [col_begin, col_begin + C) -- one BN layer of the producer side -- the epilogue forms
@@ -47,7 +52,8 @@ struct ConvP {
   int mode, flags;
   double alg_flops;       // host only: algorithmic FLOPs of this launch (profiling)
   int stages;             // host only: LDS stages (1 = two barriers per K-step, 2 = double buffered); 0 = default
-  int halo;               // host only: 1 = LDS-halo kernel (3x3 / stride 1 / pad 1 layers: input patch staged once per chunk)
+  int halo;               // host only: 1 = LDS-halo kernel (3x3 / stride 1 / pad 1 layers: input patch staged once per chunk),
+                          //            2 = LDS-DMA staging of the generic kernel
   // ---- derived by tbn_launch_conv
   unsigned in_bytes, wt_bytes;          // buffer extents: out-of-range lanes read zeros (hardware check)
   unsigned seg_bytes[TBN_CONV_MAXSEG];  // extent of each output segment from seg[i].ptr
