@@ -1234,7 +1234,9 @@ static int launch_conv_tiles(ConvP& p, int rowmode, int mt, int nt, hipStream_t 
 // passes stride 1, pad = k-1-pad_fwd and tap-flipped weights) is decomposed into the 4 output-parity
 // phases: each phase only visits the taps that hit a real (non zero-inserted) dy sample, so no MFMA
 // work is spent on inserted zeros (2.25 instead of 9 taps per output pixel for 3x3).
-int tbn_launch_conv(ConvP p, int rowmode, int mt, int nt, hipStream_t st) {
+// validation + derived fields common to every launch form; `*single` = 1 when the launch is a single GEMM
+// (up == 1: geometry completely filled), 0 when the caller still has to split it into parity phases (up == 2)
+static int conv_prepare(ConvP& p, int rowmode, int* single) {
   TBN_REQUIRE(p.K % 32 == 0 && p.Cin % 32 == 0, "conv: K (%d) and per-tap Cin (%d) must be multiples of 32", p.K,
               p.Cin);
   TBN_REQUIRE(p.in_ld % 4 == 0 && p.nseg >= 1 && p.nseg <= TBN_CONV_MAXSEG, "conv: bad in_ld %d / nseg %d", p.in_ld,
@@ -1293,8 +1295,18 @@ int tbn_launch_conv(ConvP p, int rowmode, int mt, int nt, hipStream_t st) {
     p.tnx = rowmode ? 1 : p.S;
     p.div_ohw = make_fastdiv((uint32_t)(p.OHs * p.OWs));
     p.div_ow = make_fastdiv((uint32_t)p.OWs);
-    return launch_conv_tiles(p, rowmode, mt, nt, st);
+    *single = 1;
+    return TBN_OK;
   }
+  *single = 0;
+  return TBN_OK;
+}
+
+int tbn_launch_conv(ConvP p, int rowmode, int mt, int nt, hipStream_t st) {
+  int single = 0;
+  const int prc = conv_prepare(p, rowmode, &single);
+  if (prc != TBN_OK) return prc;
+  if (single) return launch_conv_tiles(p, rowmode, mt, nt, st);
   TBN_REQUIRE(!rowmode && p.stride == 1 && p.R == p.S && p.R * p.S <= 9, "conv: unsupported strided data gradient");
   const double flops_total = p.alg_flops;
   const int full_M = p.N * p.OH * p.OW;
@@ -1403,6 +1415,105 @@ int tbn_launch_conv(ConvP p, int rowmode, int mt, int nt, hipStream_t st) {
 #undef TBN_PLAUNCH
   tbn_prof_end(st);
   TBN_CHECK_LAUNCH("conv_igemm_phases");
+  return TBN_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Two INDEPENDENT convolutions in one launch: the 3x3 and double_3x3_1 layers of an inception block read different
+// inputs and write different outputs, each alone leaves the chip partly idle on the 14x14 / 7x7 maps (259 .. 735
+// workgroups on 256 CUs) and pays its own launch ramp and last-round tail.  One grid holds the tiles of both; a
+// workgroup finds its member by a scalar compare.  Members share the tile shape, the kernel variant and the epilogue.
+struct ConvPair {
+  ConvP m[2];
+  int blk1;   // first workgroup of member 1
+};
+template <int MT, int NT, int EPI, int STAGES, bool RED>
+__global__ __launch_bounds__(256) void conv_pair_igemm_kernel(ConvPair q) {
+  __shared__ __attribute__((aligned(16))) float lds[STAGES * (128 * MT + 32 * NT) * LDT];
+  const int mi = (int)blockIdx.x >= q.blk1 ? 1 : 0;
+  conv_igemm_body<MT, NT, false, EPI, STAGES, RED>(q.m[mi], blockIdx.x - (mi ? q.blk1 : 0), lds);
+}
+template <int MT, int NT, int EPI, bool RED>
+__global__ __launch_bounds__(256) void conv_pair_halo_kernel(ConvPair q) {
+  extern __shared__ __attribute__((aligned(16))) float dyn_lds[];
+  const int mi = (int)blockIdx.x >= q.blk1 ? 1 : 0;
+  conv_halo_body<MT, NT, EPI, RED>(q.m[mi], blockIdx.x - (mi ? q.blk1 : 0), dyn_lds);
+}
+
+template <int MT, int NT, int EPI, bool RED>
+static int launch_pair_v(const ConvPair& q, int blocks, int variant, size_t lds_bytes, hipStream_t st) {
+  if (variant == 0) {   // LDS-halo members
+    static size_t allowed = 64 * 1024;
+    if (lds_bytes > allowed) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pair_halo_kernel<MT, NT, EPI, RED>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+        tbn_set_error("conv_pair: cannot raise the dynamic LDS limit");
+        return TBN_ERR_LAUNCH;
+      }
+      allowed = 160 * 1024;
+    }
+    hipLaunchKernelGGL((conv_pair_halo_kernel<MT, NT, EPI, RED>), dim3(blocks), dim3(256), lds_bytes, st, q);
+  } else if (variant == 2) {
+    hipLaunchKernelGGL((conv_pair_igemm_kernel<MT, NT, EPI, 2, RED>), dim3(blocks), dim3(256), 0, st, q);
+  } else {
+    hipLaunchKernelGGL((conv_pair_igemm_kernel<MT, NT, EPI, 1, RED>), dim3(blocks), dim3(256), 0, st, q);
+  }
+  return TBN_OK;
+}
+template <int MT, int NT>
+static int launch_pair(const ConvPair& q, int blocks, int variant, size_t lds_bytes, hipStream_t st) {
+  const ConvP& p = q.m[0];
+  if (p.mode == CONV_EPI_STATS) return launch_pair_v<MT, NT, 1, false>(q, blocks, variant, lds_bytes, st);
+  if (p.mode == CONV_EPI_EVAL) return launch_pair_v<MT, NT, 2, false>(q, blocks, variant, lds_bytes, st);
+  if (p.nred > 0) return launch_pair_v<MT, NT, 0, true>(q, blocks, variant, lds_bytes, st);
+  return launch_pair_v<MT, NT, 0, false>(q, blocks, variant, lds_bytes, st);
+}
+
+// variant: 0 LDS-halo (both members 3x3 / stride 1), 1 / 2 register-staged generic kernel with 1 / 2 LDS stages.
+// Tiles: (1,1) (1,2) (2,1) (2,2).  Both members: unit-stride launches (no parity phases), same epilogue mode, reduce
+// segments on both or on neither.
+int tbn_launch_conv_pair(ConvP a, ConvP b, int variant, int mt, int nt, hipStream_t st) {
+  static thread_local ConvPair q;
+  int sa = 0, sb = 0;
+  int rc = conv_prepare(a, 0, &sa);
+  if (rc != TBN_OK) return rc;
+  rc = conv_prepare(b, 0, &sb);
+  if (rc != TBN_OK) return rc;
+  TBN_REQUIRE(sa && sb, "conv_pair: members must be unit-stride launches (no parity phases)");
+  TBN_REQUIRE(a.mode == b.mode && (a.nred > 0) == (b.nred > 0) && a.flags == b.flags,
+              "conv_pair: members must share the epilogue");
+  TBN_REQUIRE(variant >= 0 && variant <= 2 && mt >= 1 && mt <= 2 && nt >= 1 && nt <= 2, "conv_pair: unsupported variant / tile");
+  size_t lds_bytes = 0;
+  if (variant == 0) {
+    const size_t la = tbn_conv_halo_lds_bytes(a, mt, nt), lb = tbn_conv_halo_lds_bytes(b, mt, nt);
+    TBN_REQUIRE(la > 0 && lb > 0 && la <= 160 * 1024 && lb <= 160 * 1024, "conv_pair: a member is not an LDS-halo shape");
+    lds_bytes = la > lb ? la : lb;
+  }
+  ConvP* ms[2] = {&a, &b};
+  for (int i = 0; i < 2; ++i) {
+    ms[i]->tiles_m = cdiv(ms[i]->M, 128 * mt);
+    ms[i]->tiles_n = cdiv(ms[i]->Cout, 32 * nt);
+    ms[i]->stages = variant == 2 ? 2 : 1;
+    ms[i]->halo = variant == 0 ? 1 : 0;
+    q.m[i] = *ms[i];
+  }
+  q.blk1 = a.tiles_m * a.tiles_n;
+  const int blocks = q.blk1 + b.tiles_m * b.tiles_n;
+  {
+    char nm[64];
+    const int epi = a.mode == CONV_EPI_STATS ? 1 : (a.mode == CONV_EPI_EVAL ? 2 : 0);
+    snprintf(nm, sizeof(nm), "conv_pair_%s_kernel<%d, %d, %d%s%s>", variant == 0 ? "halo" : "igemm", mt, nt, epi,
+             variant == 2 ? ", 2" : (variant == 1 ? ", 1" : ""), (a.nred > 0 && epi == 0) ? ", true" : "");
+    tbn_prof_begin(nm, a.alg_flops + b.alg_flops, st, conv_alg_bytes(a, 0) + conv_alg_bytes(b, 0));
+  }
+  rc = TBN_OK;
+  if (mt == 1 && nt == 1) rc = launch_pair<1, 1>(q, blocks, variant, lds_bytes, st);
+  if (mt == 1 && nt == 2) rc = launch_pair<1, 2>(q, blocks, variant, lds_bytes, st);
+  if (mt == 2 && nt == 1) rc = launch_pair<2, 1>(q, blocks, variant, lds_bytes, st);
+  if (mt == 2 && nt == 2) rc = launch_pair<2, 2>(q, blocks, variant, lds_bytes, st);
+  tbn_prof_end(st);
+  if (rc != TBN_OK) return rc;
+  TBN_CHECK_LAUNCH("conv_pair");
   return TBN_OK;
 }
 

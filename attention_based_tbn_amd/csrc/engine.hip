@@ -75,6 +75,11 @@ struct Conv {   // one GEMM: up to four parts that read the same input (adjacent
   int mt, nt, stages = 0;       // forward tile / LDS stages (0 = default)
   int d_mt, d_nt, d_stages = 0; // dgrad tile
   int halo = 0, d_halo = 0;     // 3x3 / stride-1 layers: LDS-halo kernel for the forward / data-gradient GEMM
+  // sibling pairing (3x3 | double_3x3_1 of a block: independent GEMMs issued as ONE launch, tbn_launch_conv_pair)
+  int pair_next = -1, pair_prev = -1;     // the first member points at the second and vice versa
+  bool pair_fwd = false, pair_dgrad = false;   // decided by the autotuner (first member holds the decision)
+  int pf_variant = 1, pf_mt = 1, pf_nt = 1, pd_variant = 1, pd_mt = 1, pd_nt = 1;
+  float t_fwd = 0.f, t_dgrad = 0.f;       // autotune: best single-launch times (ms)
   int w_mt = 0, w_nt = 0;       // wgrad tile (0 = heuristic)
   bool stem;
   bool dgrad_accum;    // dgrad adds into d(inbuf)
@@ -349,6 +354,8 @@ bool build_graph(tbn_backbone_plan* P) {
       int co = B.cd1, db = T3, dc = 0;
       mc[nm] = add_conv(P, 1, &n, &co, B.cdr, 3, 1, 1, T2, &db, &dc, false);
       P->convs[mc[nm]].slot = nm;
+      P->convs[mc[nm]].pair_prev = mc[nm - 1];
+      P->convs[mc[nm - 1]].pair_next = mc[nm];
       mp[nm++] = 0;
     }
     if (B.pool == 2) {
@@ -852,9 +859,43 @@ int tbn_backbone_forward(const tbn_backbone_plan* P, int training, const float* 
     TBN_TRY(tbn_launch_bn_fold(prm->gamma, prm->beta, prm->running_mean, prm->running_var, prm->bias, prm->eps, scale,
                                shift, (int)P->chan_floats, st));
 
+  auto fwd_params = [&](const Conv& c, ConvP& p) {
+    fill_fwd(P, c, ws, prm->weight, R, &p);
+    if (training) {
+      p.mode = CONV_EPI_STATS;
+      p.nseg = 1;
+      p.seg[0].ptr = ws + c.y_off;
+      p.seg[0].ld = c.cout;
+      p.seg[0].col_begin = 0;
+      p.stat_partial = ws + P->partial_off + (size_t)c.slot * P->partial_floats;
+    } else {
+      p.mode = CONV_EPI_EVAL;
+      p.scale = scale + c.c_off;
+      p.shift = shift + c.c_off;
+      p.nseg = c.nparts;
+      for (int i = 0; i < c.nparts; ++i) {
+        const Part& q = c.parts[i];
+        const Buf& db = P->bufs[q.dst_buf];
+        p.seg[i].ptr = q.pooled ? ws + q.yraw_off : ws + db.off + q.dst_choff;
+        p.seg[i].ld = q.pooled ? q.cout : db.C;
+        p.seg[i].col_begin = q.col0;
+        if (q.pooled) p.raw_seg1 = i + 1;
+      }
+    }
+  };
   for (const Op& o : P->ops) {
     if (o.kind == OP_CONV) {
       const Conv& c = P->convs[o.idx];
+      if (c.pair_prev >= 0 && P->convs[c.pair_prev].pair_fwd) continue;   // ran with its sibling
+      if (c.pair_next >= 0 && c.pair_fwd) {
+        const Conv& c2 = P->convs[c.pair_next];
+        ConvP pa, pb;
+        fwd_params(c, pa);
+        fwd_params(c2, pb);
+        tbn_prof_label(("fwd " + c.parts[0].name + " | " + c2.parts[0].name).c_str());
+        TBN_TRY(tbn_launch_conv_pair(pa, pb, c.pf_variant, c.pf_mt, c.pf_nt, st));
+        continue;
+      }
       ConvP p;
       fill_fwd(P, c, ws, prm->weight, R, &p);
       tbn_prof_label(("fwd " + c.parts[c.nparts - 1].name).c_str());
@@ -956,7 +997,10 @@ int tbn_backbone_forward(const tbn_backbone_plan* P, int training, const float* 
           L.y_ld = c.cout;
           L.partial = ws + P->partial_off + (size_t)c.slot * P->partial_floats + q.col0;
           L.pld = c.cout;
-          L.nparts = cdiv(M, 128 * c.mt);
+          int fmt = c.mt;      // M tile of the launch that wrote the statistics partials (a paired launch has its own)
+          if (c.pair_next >= 0 && c.pair_fwd) fmt = c.pf_mt;
+          if (c.pair_prev >= 0 && P->convs[c.pair_prev].pair_fwd) fmt = P->convs[c.pair_prev].pf_mt;
+          L.nparts = cdiv(M, 128 * fmt);
         }
         L.gamma = prm->gamma + q.c_off;
         L.beta = prm->beta + q.c_off;
@@ -1078,14 +1122,88 @@ int tbn_backbone_autotune(tbn_backbone_plan* P, int training, const tbn_backbone
         c.nt = bn;
         c.stages = bs;
         c.halo = bh;
+        c.t_fwd = best;
       } else {
         c.d_mt = bm;
         c.d_nt = bn;
         c.d_stages = bs;
         c.d_halo = bh;
+        c.t_dgrad = best;
       }
     }
     if (rc != TBN_OK) break;
+  }
+  // sibling pairs (3x3 | double_3x3_1): one launch for both when that beats the two tuned single launches
+  static const int use_pairs = getenv("TBN_USE_PAIRS") ? atoi(getenv("TBN_USE_PAIRS")) : 1;
+  for (size_t ci = 0; ci < P->convs.size() && rc == TBN_OK; ++ci) {
+    Conv& c = P->convs[ci];
+    c.pair_fwd = c.pair_dgrad = false;
+    if (c.pair_next < 0 || !use_pairs) continue;
+    Conv& c2 = P->convs[c.pair_next];
+    for (int pass = 0; pass < 2 && rc == TBN_OK; ++pass) {
+      if (pass == 1 && (!training || c.stride != 1 || c2.stride != 1)) continue;   // stride 2: parity-phase launch
+      ConvP pa, pb;
+      if (pass == 0) {
+        for (int k = 0; k < 2; ++k) {
+          Conv& m = k ? c2 : c;
+          ConvP& p = k ? pb : pa;
+          fill_fwd(P, m, ws, prm->weight, R, &p);
+          p.nseg = 1;
+          p.mode = training ? CONV_EPI_STATS : CONV_EPI_EVAL;
+          p.scale = scale + m.c_off;
+          p.shift = shift + m.c_off;
+          p.stat_partial = ws + P->partial_off + (size_t)m.slot * P->partial_floats;
+          if (training) {
+            p.seg[0].ptr = ws + m.y_off;
+            p.seg[0].ld = m.cout;
+          } else {
+            const Buf& db = P->bufs[m.parts[0].dst_buf];
+            p.seg[0].ptr = ws + db.off + m.parts[0].dst_choff;
+            p.seg[0].ld = db.C;
+          }
+        }
+      } else {
+        fill_dgrad(P, c, ws, R, &pa);
+        fill_dgrad(P, c2, ws, R, &pb);
+      }
+      float best = 1e30f;
+      int bv = 1, bm = 1, bn = 1;
+      for (int variant = 0; variant <= 2 && rc == TBN_OK; ++variant) {
+        if (variant == 0 && (tbn_conv_halo_lds_bytes(pa, 1, 1) == 0 || tbn_conv_halo_lds_bytes(pb, 1, 1) == 0)) continue;
+        for (int mt = 1; mt <= 2 && rc == TBN_OK; ++mt)
+          for (int nt = 1; nt <= 2 && rc == TBN_OK; ++nt) {
+            if (variant == 0 && (tbn_conv_halo_lds_bytes(pa, mt, nt) > 160 * 1024 || tbn_conv_halo_lds_bytes(pb, mt, nt) > 160 * 1024))
+              continue;
+            float ms = 0.f;
+            for (int rep = 0; rep < 2 && rc == TBN_OK; ++rep) {
+              (void)hipEventRecord(e0, st);
+              rc = tbn_launch_conv_pair(pa, pb, variant, mt, nt, st);
+              (void)hipEventRecord(e1, st);
+              (void)hipEventSynchronize(e1);
+              (void)hipEventElapsedTime(&ms, e0, e1);
+            }
+            if (ms < best) {
+              best = ms;
+              bv = variant;
+              bm = mt;
+              bn = nt;
+            }
+          }
+      }
+      const float singles = pass == 0 ? c.t_fwd + c2.t_fwd : c.t_dgrad + c2.t_dgrad;
+      const bool take = rc == TBN_OK && best < 0.97f * singles;
+      if (pass == 0) {
+        c.pair_fwd = take;
+        c.pf_variant = bv;
+        c.pf_mt = bm;
+        c.pf_nt = bn;
+      } else {
+        c.pair_dgrad = take;
+        c.pd_variant = bv;
+        c.pd_mt = bm;
+        c.pd_nt = bn;
+      }
+    }
   }
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
@@ -1204,7 +1322,10 @@ int tbn_backbone_backward(const tbn_backbone_plan* P, const float* dfeatures, co
           // S1 / S2 partials were formed by the data-gradient epilogue that finished dz (conv RedSeg)
           const Conv& f = P->convs[q.red_src];
           L.partial = ws + q.bpart_off;
-          L.ext_parts = tbn_conv_red_rows(R, f.inH, f.inW, f.stride, f.d_mt);
+          int dmt = f.d_mt;    // M tile of the launch that wrote the partials (a paired launch has its own tile)
+          if (f.pair_next >= 0 && f.pair_dgrad) dmt = f.pd_mt;
+          if (f.pair_prev >= 0 && P->convs[f.pair_prev].pair_dgrad) dmt = P->convs[f.pair_prev].pd_mt;
+          L.ext_parts = tbn_conv_red_rows(R, f.inH, f.inW, f.stride, dmt);
         } else {
           L.partial = partial + (size_t)k * P->partial_floats;
           L.ext_parts = 0;
@@ -1246,6 +1367,16 @@ int tbn_backbone_backward(const tbn_backbone_plan* P, const float* dfeatures, co
       }
     }
     if (c.need_dgrad) {
+      if (c.pair_prev >= 0 && P->convs[c.pair_prev].pair_dgrad) continue;   // issued with its sibling (next in this walk)
+      if (c.pair_next >= 0 && c.pair_dgrad) {
+        const Conv& c2 = P->convs[c.pair_next];
+        ConvP pa, pb;
+        fill_dgrad(P, c, ws, R, &pa);
+        fill_dgrad(P, c2, ws, R, &pb);
+        tbn_prof_label(("dgrad " + c.parts[0].name + " | " + c2.parts[0].name).c_str());
+        TBN_TRY(tbn_launch_conv_pair(pa, pb, c.pd_variant, c.pd_mt, c.pd_nt, st));
+        continue;
+      }
       tbn_prof_label(("dgrad " + c.parts[c.nparts - 1].name).c_str());
       ConvP p;
       fill_dgrad(P, c, ws, R, &p);

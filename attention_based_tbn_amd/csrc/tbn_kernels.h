@@ -97,6 +97,8 @@ void tbn_prof_label(const char* label);
 // conv_igemm.hip
 void tbn_conv_pick_tile(int M, int Cout, int K, int* mt, int* nt);
 int tbn_launch_conv(ConvP p, int rowmode, int mt, int nt, hipStream_t st);
+// two independent unit-stride convs in one launch (variant 0 LDS-halo, 1 / 2 generic with 1 / 2 LDS stages; tiles <= (2,2))
+int tbn_launch_conv_pair(ConvP a, ConvP b, int variant, int mt, int nt, hipStream_t st);
 int tbn_conv_red_rows(int N, int OH, int OW, int up, int mt);
 size_t tbn_conv_halo_lds_bytes(const ConvP& p, int mt, int nt);   // 0: shape not handled by the LDS-halo kernel
 void tbn_wgrad_plan(int M, int Cout, int Cin, int taps, int* mt, int* nt, int* splits, int* rows_per_split);
