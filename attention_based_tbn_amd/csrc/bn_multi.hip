@@ -57,42 +57,78 @@ __global__ __launch_bounds__(256) void bn_finalize_multi_kernel(BnFwdBatch b) {
 }
 
 // ---------------------------------------------------------------- forward: apply z = relu(y*scale+shift)
+// A thread owns ONE float4 channel quad (tid % G) and walks rows tid / G, + RP, ... of its workgroup's row block: the
+// per-channel scale / shift are loaded once per thread and the element index needs no division (the former flat
+// grid-stride form spent ~20 VALU instructions per float4 on i / G and re-read scale / shift for every element --
+// VALU these HBM-bound kernels take from the fp32 MFMAs running beside them).  Four rows in flight per thread.
 __global__ __launch_bounds__(256) void bn_apply_multi_kernel(BnFwdBatch b) {
   const int li = find_layer(b.app_blk0, b.n, blockIdx.x);
   const BnFwdLayer& L = b.l[li];
-  const int blk = blockIdx.x - b.app_blk0[li], grid = b.app_blk0[li + 1] - b.app_blk0[li];
-  const int C = L.C, G = C >> 2;
-  const size_t total = (size_t)L.P * G;
-  const float* y = L.y;
-  const int yld = L.y_ld;
-  for (size_t i = (size_t)blk * 256 + threadIdx.x; i < total; i += (size_t)grid * 256) {
-    const int p = (int)(i / G), c = (int)(i - (size_t)p * G) * 4;
-    const float4 v = *reinterpret_cast<const float4*>(y + (size_t)p * yld + c);
-    const float4 sc = *reinterpret_cast<const float4*>(L.scale + c);
-    const float4 sh = *reinterpret_cast<const float4*>(L.shift + c);
+  const int blk = blockIdx.x - b.app_blk0[li];
+  const int G = L.C >> 2, RP = 256 / G;
+  const int cg = threadIdx.x % G, rs = threadIdx.x / G;
+  if (rs >= RP) return;
+  const int c = cg * 4;
+  const int p0 = blk * L.app_rows, p1 = min(L.P, p0 + L.app_rows);
+  const float4 sc = *reinterpret_cast<const float4*>(L.scale + c);
+  const float4 sh = *reinterpret_cast<const float4*>(L.shift + c);
+  int sg = 0;
+  if (L.nseg > 1 && c >= L.seg[1].col_begin) sg = 1;
+  if (L.nseg > 2 && c >= L.seg[2].col_begin) sg = 2;
+  const float* yp = L.y + (size_t)(p0 + rs) * L.y_ld + c;
+  float* zp = L.seg[sg].ptr + (size_t)(p0 + rs) * L.seg[sg].ld + (c - L.seg[sg].col_begin);
+  const size_t ystep = (size_t)RP * L.y_ld, zstep = (size_t)RP * L.seg[sg].ld;
+  int p = p0 + rs;
+  for (; p + 3 * RP < p1; p += 4 * RP) {
+    float4 v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = *reinterpret_cast<const float4*>(yp + k * ystep);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float4 z;
+      z.x = fmaxf(fmaf(v[k].x, sc.x, sh.x), 0.f);
+      z.y = fmaxf(fmaf(v[k].y, sc.y, sh.y), 0.f);
+      z.z = fmaxf(fmaf(v[k].z, sc.z, sh.z), 0.f);
+      z.w = fmaxf(fmaf(v[k].w, sc.w, sh.w), 0.f);
+      *reinterpret_cast<float4*>(zp + k * zstep) = z;
+    }
+    yp += 4 * ystep;
+    zp += 4 * zstep;
+  }
+  for (; p < p1; p += RP) {
+    const float4 v = *reinterpret_cast<const float4*>(yp);
     float4 z;
     z.x = fmaxf(fmaf(v.x, sc.x, sh.x), 0.f);
     z.y = fmaxf(fmaf(v.y, sc.y, sh.y), 0.f);
     z.z = fmaxf(fmaf(v.z, sc.z, sh.z), 0.f);
     z.w = fmaxf(fmaf(v.w, sc.w, sh.w), 0.f);
-    int sg = 0;
-    if (L.nseg > 1 && c >= L.seg[1].col_begin) sg = 1;
-    if (L.nseg > 2 && c >= L.seg[2].col_begin) sg = 2;
-    *reinterpret_cast<float4*>(L.seg[sg].ptr + (size_t)p * L.seg[sg].ld + (c - L.seg[sg].col_begin)) = z;
+    *reinterpret_cast<float4*>(zp) = z;
+    yp += ystep;
+    zp += zstep;
   }
+}
+
+// rows per workgroup of the apply kernels: 4 .. 16 passes of the row lanes, aiming at ~2048 workgroups per layer
+static inline int apply_rows(int P, int C) {
+  const int RP = 256 / (C / 4);
+  int it = cdiv(P, RP * 2048);
+  if (it < 4) it = 4;
+  if (it > 16) it = 16;
+  return RP * it;
 }
 
 int tbn_launch_bn_fwd_multi(BnFwdBatch& b, hipStream_t st) {
   TBN_REQUIRE(b.n >= 1 && b.n <= TBN_BN_MAXL, "bn_fwd_multi: %d layers", b.n);
   b.fin_blk0[0] = b.app_blk0[0] = 0;
   for (int i = 0; i < b.n; ++i) {
-    const BnFwdLayer& L = b.l[i];
-    TBN_REQUIRE(L.C % 4 == 0 && L.y_ld % 4 == 0 && L.y_ld >= L.C && L.pld >= L.C && L.nseg >= 1 && L.nseg <= 3,
+    BnFwdLayer& L = b.l[i];
+    TBN_REQUIRE(L.C % 4 == 0 && L.C <= 1024 && L.y_ld % 4 == 0 && L.y_ld >= L.C && L.pld >= L.C && L.nseg >= 1 && L.nseg <= 3,
                 "bn_fwd_multi: bad C / pitch / nseg");
     for (int s = 0; s < L.nseg; ++s)
       TBN_REQUIRE(L.seg[s].ld % 4 == 0 && L.seg[s].col_begin % 4 == 0, "bn_fwd_multi: segment pitch/offset must be x4");
     b.fin_blk0[i + 1] = b.fin_blk0[i] + cdiv(L.C, 16);
-    b.app_blk0[i + 1] = b.app_blk0[i] + ew_grid((size_t)L.P * L.C / 4);
+    L.app_rows = apply_rows(L.P, L.C);
+    b.app_blk0[i + 1] = b.app_blk0[i] + cdiv(L.P, L.app_rows);
   }
   hipLaunchKernelGGL(bn_finalize_multi_kernel, dim3(b.fin_blk0[b.n]), dim3(256), 0, st, b);
   TBN_CHECK_LAUNCH("bn_finalize_multi");
@@ -176,34 +212,56 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_multi_kernel(BnBwdBatch b
   }
 }
 
-// y and dy alias (the engine converts y to dy in place)
+// y and dy alias (the engine converts y to dy in place).  Same thread mapping as bn_apply_multi_kernel: per-channel
+// coefficients loaded once per thread, no index division, four rows in flight.
 __global__ __launch_bounds__(256) void bn_bwd_apply_multi_kernel(BnBwdBatch b) {
   const int li = find_layer(b.app_blk0, b.n, blockIdx.x);
   const BnBwdLayer& L = b.l[li];
-  const int blk = blockIdx.x - b.app_blk0[li], grid = b.app_blk0[li + 1] - b.app_blk0[li];
-  const int C = L.C, G = C >> 2;
-  const size_t total = (size_t)L.P * G;
-  const float* y = L.y;
-  float* dy = L.dy;
-  const int yld = L.y_ld;
-  for (size_t i = (size_t)blk * 256 + threadIdx.x; i < total; i += (size_t)grid * 256) {
-    const int p = (int)(i / G), c = (int)(i - (size_t)p * G) * 4;
-    int sg = 0;
-    if (L.nseg > 1 && c >= L.dz[1].col_begin) sg = 1;
-    if (L.nseg > 2 && c >= L.dz[2].col_begin) sg = 2;
-    const float4 d = *reinterpret_cast<const float4*>(L.dz[sg].ptr + (size_t)p * L.dz[sg].ld + (c - L.dz[sg].col_begin));
-    const float4 v = *reinterpret_cast<const float4*>(y + (size_t)p * yld + c);
-    const float4 sc = *reinterpret_cast<const float4*>(L.scale + c);
-    const float4 sh = *reinterpret_cast<const float4*>(L.shift + c);
-    const float4 ca = *reinterpret_cast<const float4*>(L.coef + c);
-    const float4 cb = *reinterpret_cast<const float4*>(L.coef + C + c);
-    const float4 cc = *reinterpret_cast<const float4*>(L.coef + 2 * C + c);
+  const int blk = blockIdx.x - b.app_blk0[li];
+  const int C = L.C, G = C >> 2, RP = 256 / G;
+  const int cg = threadIdx.x % G, rs = threadIdx.x / G;
+  if (rs >= RP) return;
+  const int c = cg * 4;
+  const int p0 = blk * L.app_rows, p1 = min(L.P, p0 + L.app_rows);
+  int sg = 0;
+  if (L.nseg > 1 && c >= L.dz[1].col_begin) sg = 1;
+  if (L.nseg > 2 && c >= L.dz[2].col_begin) sg = 2;
+  const float4 sc = *reinterpret_cast<const float4*>(L.scale + c);
+  const float4 sh = *reinterpret_cast<const float4*>(L.shift + c);
+  const float4 ca = *reinterpret_cast<const float4*>(L.coef + c);
+  const float4 cb = *reinterpret_cast<const float4*>(L.coef + C + c);
+  const float4 cc = *reinterpret_cast<const float4*>(L.coef + 2 * C + c);
+  const float* dp = L.dz[sg].ptr + (size_t)(p0 + rs) * L.dz[sg].ld + (c - L.dz[sg].col_begin);
+  const float* yp = L.y + (size_t)(p0 + rs) * L.y_ld + c;
+  float* op = L.dy + (size_t)(p0 + rs) * L.y_ld + c;
+  const size_t dstep = (size_t)RP * L.dz[sg].ld, ystep = (size_t)RP * L.y_ld;
+  auto one = [&](const float4 d, const float4 v) {
     float4 o;
     o.x = fmaf(ca.x, fmaf(v.x, sc.x, sh.x) > 0.f ? d.x : 0.f, fmaf(cb.x, v.x, cc.x));
     o.y = fmaf(ca.y, fmaf(v.y, sc.y, sh.y) > 0.f ? d.y : 0.f, fmaf(cb.y, v.y, cc.y));
     o.z = fmaf(ca.z, fmaf(v.z, sc.z, sh.z) > 0.f ? d.z : 0.f, fmaf(cb.z, v.z, cc.z));
     o.w = fmaf(ca.w, fmaf(v.w, sc.w, sh.w) > 0.f ? d.w : 0.f, fmaf(cb.w, v.w, cc.w));
-    *reinterpret_cast<float4*>(dy + (size_t)p * yld + c) = o;
+    return o;
+  };
+  int p = p0 + rs;
+  for (; p + 3 * RP < p1; p += 4 * RP) {
+    float4 d[4], v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      d[k] = *reinterpret_cast<const float4*>(dp + k * dstep);
+      v[k] = *reinterpret_cast<const float4*>(yp + k * ystep);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) *reinterpret_cast<float4*>(op + k * ystep) = one(d[k], v[k]);
+    dp += 4 * dstep;
+    yp += 4 * ystep;
+    op += 4 * ystep;
+  }
+  for (; p < p1; p += RP) {
+    *reinterpret_cast<float4*>(op) = one(*reinterpret_cast<const float4*>(dp), *reinterpret_cast<const float4*>(yp));
+    dp += dstep;
+    yp += ystep;
+    op += ystep;
   }
 }
 
@@ -230,7 +288,8 @@ int tbn_launch_bn_bwd_multi(BnBwdBatch& b, hipStream_t st) {
     }
     b.red_blk0[i + 1] = b.red_blk0[i] + red_blocks;
     b.fin_blk0[i + 1] = b.fin_blk0[i] + cdiv(L.C, 16);
-    b.app_blk0[i + 1] = b.app_blk0[i] + ew_grid((size_t)L.P * L.C / 4);
+    L.app_rows = apply_rows(L.P, L.C);
+    b.app_blk0[i + 1] = b.app_blk0[i] + cdiv(L.P, L.app_rows);
   }
   if (b.red_blk0[b.n] > 0) {
     hipLaunchKernelGGL(bn_bwd_reduce_multi_kernel, dim3(b.red_blk0[b.n]), dim3(256), 0, st, b);

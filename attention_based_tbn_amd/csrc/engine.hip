@@ -1055,6 +1055,21 @@ int tbn_backbone_autotune(tbn_backbone_plan* P, int training, const tbn_backbone
   // candidates are timed one at a time: whatever other streams still run (the other modality backbones of a first
   // step) would make the choice depend on what happened to overlap -> drain the device first
   (void)hipDeviceSynchronize();
+  // all candidates of one GEMM are enqueued back to back, each between its own pair of events, and the host waits
+  // ONCE per GEMM (a host round trip per candidate cost more than the small layers' kernels themselves)
+  constexpr int kMaxCand = 40;
+  hipEvent_t ce[2 * kMaxCand];
+  for (int i = 0; i < 2 * kMaxCand; ++i) {
+    ce[i] = nullptr;
+    if (hipEventCreate(&ce[i]) != hipSuccess) {
+      tbn_set_error("autotune: hipEventCreate failed");
+      for (int k = 0; k < i; ++k) (void)hipEventDestroy(ce[k]);
+      (void)hipEventDestroy(e0);
+      (void)hipEventDestroy(e1);
+      return TBN_ERR_LAUNCH;
+    }
+  }
+  struct Cand { int mt, nt, stages, halo; };
   int rc = TBN_OK;
   for (auto& c : P->convs) {
     for (int pass = 0; pass < 2 && rc == TBN_OK; ++pass) {  // 0: forward, 1: data gradient
@@ -1086,6 +1101,8 @@ int tbn_backbone_autotune(tbn_backbone_plan* P, int training, const tbn_backbone
       float best = 1e30f;
       int bm = 1, bn = 1, bs = 2, bh = 0;
       static const int force_halo = getenv("TBN_FORCE_HALO") ? atoi(getenv("TBN_FORCE_HALO")) : -1;   // tests: 0 / 1
+      Cand cand[kMaxCand];
+      int ncand = 0;
       for (int mt = 1; mt <= 2 && rc == TBN_OK; ++mt)
         for (int nt = 1; nt <= 4 && rc == TBN_OK; ++nt)
           for (int stg = 0; stg <= 3 && rc == TBN_OK; ++stg) {   // 0: LDS-halo kernel (3x3 / stride-1 layers), 3: LDS-DMA
@@ -1100,23 +1117,26 @@ int tbn_backbone_autotune(tbn_backbone_plan* P, int training, const tbn_backbone
             } else if (force_halo == 1 && !(c.stem && pass == 0) && tbn_conv_halo_lds_bytes(p, 1, 1) > 0) {
               continue;
             }
-            float ms = 0.f;
             p.stages = stg == 3 ? 2 : stg;
-            for (int rep = 0; rep < 2 && rc == TBN_OK; ++rep) {
-              (void)hipEventRecord(e0, st);
-              rc = tbn_launch_conv(p, c.stem && pass == 0, mt, nt, st);
-              (void)hipEventRecord(e1, st);
-              (void)hipEventSynchronize(e1);
-              (void)hipEventElapsedTime(&ms, e0, e1);
-            }
-            if (ms < best) {
-              best = ms;
-              bm = mt;
-              bn = nt;
-              bs = p.stages;
-              bh = p.halo;
-            }
+            if (ncand >= kMaxCand) continue;
+            rc = tbn_launch_conv(p, c.stem && pass == 0, mt, nt, st);     // untimed first run of the candidate
+            (void)hipEventRecord(ce[2 * ncand], st);
+            if (rc == TBN_OK) rc = tbn_launch_conv(p, c.stem && pass == 0, mt, nt, st);
+            (void)hipEventRecord(ce[2 * ncand + 1], st);
+            cand[ncand++] = {mt, nt, p.stages, p.halo};
           }
+      if (ncand > 0) (void)hipEventSynchronize(ce[2 * ncand - 1]);
+      for (int k = 0; k < ncand && rc == TBN_OK; ++k) {
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, ce[2 * k], ce[2 * k + 1]);
+        if (ms < best) {
+          best = ms;
+          bm = cand[k].mt;
+          bn = cand[k].nt;
+          bs = cand[k].stages;
+          bh = cand[k].halo;
+        }
+      }
       if (pass == 0) {
         c.mt = bm;
         c.nt = bn;
@@ -1168,27 +1188,32 @@ int tbn_backbone_autotune(tbn_backbone_plan* P, int training, const tbn_backbone
       }
       float best = 1e30f;
       int bv = 1, bm = 1, bn = 1;
+      Cand cand[kMaxCand];
+      int ncand = 0;
       for (int variant = 0; variant <= 2 && rc == TBN_OK; ++variant) {
         if (variant == 0 && (tbn_conv_halo_lds_bytes(pa, 1, 1) == 0 || tbn_conv_halo_lds_bytes(pb, 1, 1) == 0)) continue;
         for (int mt = 1; mt <= 2 && rc == TBN_OK; ++mt)
           for (int nt = 1; nt <= 2 && rc == TBN_OK; ++nt) {
             if (variant == 0 && (tbn_conv_halo_lds_bytes(pa, mt, nt) > 160 * 1024 || tbn_conv_halo_lds_bytes(pb, mt, nt) > 160 * 1024))
               continue;
-            float ms = 0.f;
-            for (int rep = 0; rep < 2 && rc == TBN_OK; ++rep) {
-              (void)hipEventRecord(e0, st);
-              rc = tbn_launch_conv_pair(pa, pb, variant, mt, nt, st);
-              (void)hipEventRecord(e1, st);
-              (void)hipEventSynchronize(e1);
-              (void)hipEventElapsedTime(&ms, e0, e1);
-            }
-            if (ms < best) {
-              best = ms;
-              bv = variant;
-              bm = mt;
-              bn = nt;
-            }
+            if (ncand >= kMaxCand) continue;
+            rc = tbn_launch_conv_pair(pa, pb, variant, mt, nt, st);
+            (void)hipEventRecord(ce[2 * ncand], st);
+            if (rc == TBN_OK) rc = tbn_launch_conv_pair(pa, pb, variant, mt, nt, st);
+            (void)hipEventRecord(ce[2 * ncand + 1], st);
+            cand[ncand++] = {mt, nt, variant, 0};
           }
+      }
+      if (ncand > 0) (void)hipEventSynchronize(ce[2 * ncand - 1]);
+      for (int k = 0; k < ncand && rc == TBN_OK; ++k) {
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, ce[2 * k], ce[2 * k + 1]);
+        if (ms < best) {
+          best = ms;
+          bm = cand[k].mt;
+          bn = cand[k].nt;
+          bv = cand[k].stages;
+        }
       }
       const float singles = pass == 0 ? c.t_fwd + c2.t_fwd : c.t_dgrad + c2.t_dgrad;
       const bool take = rc == TBN_OK && best < 0.97f * singles;
@@ -1207,6 +1232,7 @@ int tbn_backbone_autotune(tbn_backbone_plan* P, int training, const tbn_backbone
   }
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
+  for (int i = 0; i < 2 * kMaxCand; ++i) (void)hipEventDestroy(ce[i]);
   return rc;
 }
 

@@ -144,6 +144,7 @@ struct BnFwdLayer {
   float *running_mean, *running_var, *save_mean, *save_rstd, *scale, *shift;
   Seg seg[3];               // destination column ranges of z
   int nseg;
+  int app_rows;             // filled by the launcher: rows per workgroup of the apply kernel
 };
 struct BnFwdBatch {
   int n;
@@ -164,6 +165,7 @@ struct BnBwdLayer {
   float* coef;              // scratch [3][C]
   float *dgamma, *dbeta, *dbias;
   int pch, nparts;          // filled by the launcher
+  int app_rows;             // filled by the launcher: rows per workgroup of the apply kernel
 };
 struct BnBwdBatch {
   int n;
