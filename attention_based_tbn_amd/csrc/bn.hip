@@ -118,11 +118,11 @@ struct CSeg3 {
 
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ y, int P, int C,
                                                        const float* __restrict__ scale,
-                                                       const float* __restrict__ shift, Seg3 segs) {
+                                                       const float* __restrict__ shift, Seg3 segs, FastDiv divg) {
   const int G = C >> 2;
-  const size_t total = (size_t)P * G;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-    const int p = (int)(i / G), c = (int)(i - (size_t)p * G) * 4;
+  const uint32_t total = (uint32_t)P * G;
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+    const int p = (int)fdiv(i, divg), c = (int)(i - (uint32_t)p * (uint32_t)G) * 4;
     const float4 v = *reinterpret_cast<const float4*>(y + (size_t)p * C + c);
     const float4 sc = *reinterpret_cast<const float4*>(scale + c);
     const float4 sh = *reinterpret_cast<const float4*>(shift + c);
@@ -152,7 +152,9 @@ int tbn_launch_bn_apply(const float* y, int P, int C, const float* scale, const 
     s3.s[i] = segs[i];
     TBN_REQUIRE(segs[i].ld % 4 == 0 && segs[i].col_begin % 4 == 0, "bn_apply: segment pitch/offset must be x4");
   }
-  hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid((size_t)P * C / 4)), dim3(256), 0, st, y, P, C, scale, shift, s3);
+  TBN_REQUIRE((size_t)P * (C / 4) < (1ull << 31), "bn_apply: too many elements per call");
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid((size_t)P * C / 4)), dim3(256), 0, st, y, P, C, scale, shift, s3,
+                     make_fastdiv((uint32_t)(C / 4)));
   TBN_CHECK_LAUNCH("bn_apply");
   return TBN_OK;
 }
@@ -188,18 +190,16 @@ __global__ __launch_bounds__(256) void bn_apply_maxpool_kernel(const float* __re
                                                                const float* __restrict__ shift,
                                                                float* __restrict__ out, int out_ld,
                                                                unsigned char* __restrict__ argmax, int OH, int OW,
-                                                               int stride, int pad) {
+                                                               int stride, int pad, PixDecode dec) {
   const int G = C >> 2;
-  const size_t total = (size_t)N * OH * OW * G;
+  const uint32_t total = (uint32_t)N * OH * OW * G;
   const unsigned nb = gridDim.x, bid = blockIdx.x;   // XCD-aware order: a window row is fetched into one L2
   const unsigned q8 = nb >> 3, r8 = nb & 7, xcd = bid & 7, idx = bid >> 3;
-  const size_t b0 = (size_t)((xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx);
-  for (size_t i = b0 * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-    const int g = (int)(i % G);
-    size_t pix = i / G;
-    const int ox = (int)(pix % OW);
-    pix /= OW;
-    const int oy = (int)(pix % OH), n = (int)(pix / OH);
+  const uint32_t b0 = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+  for (uint32_t i = b0 * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+    int g, ox, oy, n;
+    uint32_t opix;
+    pix_decode(dec, i, g, ox, oy, n, opix);
     const int y0 = oy * stride - pad, x0 = ox * stride - pad;
     const float4 sc = *reinterpret_cast<const float4*>(scale + g * 4);
     const float4 sh = *reinterpret_cast<const float4*>(shift + g * 4);
@@ -224,9 +224,8 @@ __global__ __launch_bounds__(256) void bn_apply_maxpool_kernel(const float* __re
           if (z.w > best.w || z.w != z.w) { best.w = z.w; bw = k; }
         }
       }
-    const size_t opix = (size_t)(n * OH + oy) * OW + ox;
-    *reinterpret_cast<float4*>(out + opix * out_ld + g * 4) = best;
-    *reinterpret_cast<uint32_t*>(argmax + opix * C + g * 4) =
+    *reinterpret_cast<float4*>(out + (size_t)opix * out_ld + g * 4) = best;
+    *reinterpret_cast<uint32_t*>(argmax + (size_t)opix * C + g * 4) =
         (uint32_t)bx | ((uint32_t)by << 8) | ((uint32_t)bz << 16) | ((uint32_t)bw << 24);
   }
 }
@@ -237,8 +236,9 @@ int tbn_launch_bn_apply_maxpool(const float* y, int N, int H, int W, int C, cons
   TBN_REQUIRE(C % 4 == 0 && out_ld % 4 == 0 && argmax != nullptr, "bn_apply_maxpool: bad C / pitch / argmax");
   size_t g = ((size_t)N * OH * OW * (C / 4) + 255) / 256;
   if (g > 8192) g = 8192;
+  TBN_REQUIRE((size_t)N * H * W * (C / 4) < (1ull << 31), "bn_apply_maxpool: too many elements per call");
   hipLaunchKernelGGL(bn_apply_maxpool_kernel, dim3((unsigned)(g < 1 ? 1 : g)), dim3(256), 0, st, y, N, H, W, C, scale,
-                     shift, out, out_ld, argmax, OH, OW, stride, pad);
+                     shift, out, out_ld, argmax, OH, OW, stride, pad, make_pixdecode(C / 4, OW, OH));
   TBN_CHECK_LAUNCH("bn_apply_maxpool");
   return TBN_OK;
 }
@@ -456,11 +456,11 @@ template <bool POOLED>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(CSeg3 dz, PoolGrad pg, const float* y, int P, int C,
                                                            const float* __restrict__ scale,
                                                            const float* __restrict__ shift,
-                                                           const float* __restrict__ coef, float* dy) {
+                                                           const float* __restrict__ coef, float* dy, FastDiv divg) {
   const int G = C >> 2;
-  const size_t total = (size_t)P * G;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-    const int p = (int)(i / G), c = (int)(i - (size_t)p * G) * 4;
+  const uint32_t total = (uint32_t)P * G;
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+    const int p = (int)fdiv(i, divg), c = (int)(i - (uint32_t)p * (uint32_t)G) * 4;
     int sg = 0;
     if (dz.n > 1 && c >= dz.s[1].col_begin) sg = 1;
     if (dz.n > 2 && c >= dz.s[2].col_begin) sg = 2;
@@ -487,8 +487,9 @@ int tbn_launch_bn_bwd_apply(const CSeg* dz, int nseg, const float* y, int P, int
   CSeg3 s3;
   TBN_REQUIRE(C % 4 == 0 && nseg >= 1 && nseg <= 3 && fill_cseg3(&s3, dz, nseg) == 0, "bn_bwd_apply: bad segments");
   PoolGrad none = {};
+  TBN_REQUIRE((size_t)P * (C / 4) < (1ull << 31), "bn_bwd_apply: too many elements per call");
   hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(ew_grid((size_t)P * C / 4)), dim3(256), 0, st, s3, none, y, P, C,
-                     scale, shift, coef, dy);
+                     scale, shift, coef, dy, make_fastdiv((uint32_t)(C / 4)));
   TBN_CHECK_LAUNCH("bn_bwd_apply");
   return TBN_OK;
 }
@@ -502,7 +503,7 @@ int tbn_launch_bn_bwd_apply_pooled(const float* dpooled, int dpooled_ld, const u
   s3.n = 1;
   hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(ew_grid((size_t)P * C / 4)), dim3(256), 0, st, s3,
                      make_poolgrad(dpooled, dpooled_ld, argmax, H, W, OH, OW, C, stride, pad), y, P, C, scale, shift,
-                     coef, dy);
+                     coef, dy, make_fastdiv((uint32_t)(C / 4)));
   TBN_CHECK_LAUNCH("bn_bwd_apply_pooled");
   return TBN_OK;
 }

@@ -18,24 +18,22 @@ static inline int ew_grid(size_t items) {
 // Stencil kernels re-read their neighbours' rows: workgroups b, b+8, ... share an XCD (and its L2), so the
 // bijective remap hands every XCD a CONTIGUOUS run of workgroup ids -- a row is then fetched into one L2, not
 // into all eight (measured: 3x the algorithmic HBM reads without it).
-__device__ __forceinline__ size_t xcd_block_id() {
+__device__ __forceinline__ unsigned xcd_block_id() {
   const unsigned nb = gridDim.x, bid = blockIdx.x;
   const unsigned q8 = nb >> 3, r8 = nb & 7, xcd = bid & 7, idx = bid >> 3;
-  return (size_t)((xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx);
+  return (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
 }
 
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ in, int in_ld,
                                                           float* __restrict__ out, int out_ld,
                                                           uint8_t* __restrict__ argmax, int N, int H, int W, int C,
-                                                          int OH, int OW, int stride, int pad) {
+                                                          int OH, int OW, int stride, int pad, PixDecode dec) {
   const int G = C >> 2;
-  const size_t total = (size_t)N * OH * OW * G;
-  for (size_t i = xcd_block_id() * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-    const int g = (int)(i % G);
-    size_t pix = i / G;
-    const int ox = (int)(pix % OW);
-    pix /= OW;
-    const int oy = (int)(pix % OH), n = (int)(pix / OH);
+  const uint32_t total = (uint32_t)N * OH * OW * G;
+  for (uint32_t i = xcd_block_id() * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+    int g, ox, oy, n;
+    uint32_t opix;
+    pix_decode(dec, i, g, ox, oy, n, opix);
     const int y0 = oy * stride - pad, x0 = ox * stride - pad;
     float4 best = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
     int bx = 0, by = 0, bz = 0, bw = 0;
@@ -53,10 +51,9 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restric
           if (v.w > best.w || v.w != v.w) { best.w = v.w; bw = k; }
         }
       }
-    const size_t opix = (size_t)(n * OH + oy) * OW + ox;
-    *reinterpret_cast<float4*>(out + opix * out_ld + g * 4) = best;
+    *reinterpret_cast<float4*>(out + (size_t)opix * out_ld + g * 4) = best;
     if (argmax != nullptr)
-      *reinterpret_cast<uint32_t*>(argmax + opix * C + g * 4) =
+      *reinterpret_cast<uint32_t*>(argmax + (size_t)opix * C + g * 4) =
           (uint32_t)bx | ((uint32_t)by << 8) | ((uint32_t)bz << 16) | ((uint32_t)bw << 24);
   }
 }
@@ -64,8 +61,9 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restric
 int tbn_launch_maxpool_fwd(const float* in, int in_ld, float* out, int out_ld, uint8_t* argmax, int N, int H, int W,
                            int C, int OH, int OW, int stride, int pad, hipStream_t st) {
   TBN_REQUIRE(C % 4 == 0 && in_ld % 4 == 0 && out_ld % 4 == 0, "maxpool: C / pitches must be multiples of 4");
+  TBN_REQUIRE((size_t)N * H * W * (C / 4) < (1ull << 31), "maxpool: too many elements per call");
   hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(ew_grid((size_t)N * OH * OW * C / 4)), dim3(256), 0, st, in, in_ld, out,
-                     out_ld, argmax, N, H, W, C, OH, OW, stride, pad);
+                     out_ld, argmax, N, H, W, C, OH, OW, stride, pad, make_pixdecode(C / 4, OW, OH));
   TBN_CHECK_LAUNCH("maxpool_fwd");
   return TBN_OK;
 }
@@ -74,15 +72,14 @@ int tbn_launch_maxpool_fwd(const float* in, int in_ld, float* out, int out_ld, u
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ dout, int dout_ld,
                                                           const uint8_t* __restrict__ argmax,
                                                           float* __restrict__ din, int din_ld, int N, int H, int W,
-                                                          int C, int OH, int OW, int stride, int pad, int accumulate) {
+                                                          int C, int OH, int OW, int stride, int pad, int accumulate,
+                                                          PixDecode dec) {
   const int G = C >> 2;
-  const size_t total = (size_t)N * H * W * G;
-  for (size_t i = xcd_block_id() * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-    const int g = (int)(i % G);
-    size_t pix = i / G;
-    const int ix = (int)(pix % W);
-    pix /= W;
-    const int iy = (int)(pix % H), n = (int)(pix / H);
+  const uint32_t total = (uint32_t)N * H * W * G;
+  for (uint32_t i = xcd_block_id() * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+    int g, ix, iy, n;
+    uint32_t ipix;
+    pix_decode(dec, i, g, ix, iy, n, ipix);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (stride == 2 && pad == 0) {
       // the pass-through pools of inception_3c / 4e: branch-free form of the loops below (window i >> 1 with tap
@@ -133,7 +130,7 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
       }
     }
     }
-    float4* o = reinterpret_cast<float4*>(din + ((size_t)(n * H + iy) * W + ix) * din_ld + g * 4);
+    float4* o = reinterpret_cast<float4*>(din + (size_t)ipix * din_ld + g * 4);
     if (accumulate) {
       const float4 prev = *o;
       acc.x += prev.x; acc.y += prev.y; acc.z += prev.z; acc.w += prev.w;
@@ -145,8 +142,9 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
 int tbn_launch_maxpool_bwd(const float* dout, int dout_ld, const uint8_t* argmax, float* din, int din_ld, int N,
                            int H, int W, int C, int OH, int OW, int stride, int pad, int accumulate, hipStream_t st) {
   TBN_REQUIRE(C % 4 == 0 && din_ld % 4 == 0 && dout_ld % 4 == 0, "maxpool_bwd: C / pitches must be multiples of 4");
+  TBN_REQUIRE((size_t)N * H * W * (C / 4) < (1ull << 31), "maxpool_bwd: too many elements per call");
   hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(ew_grid((size_t)N * H * W * C / 4)), dim3(256), 0, st, dout, dout_ld,
-                     argmax, din, din_ld, N, H, W, C, OH, OW, stride, pad, accumulate);
+                     argmax, din, din_ld, N, H, W, C, OH, OW, stride, pad, accumulate, make_pixdecode(C / 4, W, H));
   TBN_CHECK_LAUNCH("maxpool_bwd");
   return TBN_OK;
 }
@@ -154,15 +152,13 @@ int tbn_launch_maxpool_bwd(const float* dout, int dout_ld, const uint8_t* argmax
 // 3x3 / stride 1 / pad 1 / count_include_pad average.  Self-adjoint, so it is its own backward.
 __global__ __launch_bounds__(256) void avgpool3_kernel(const float* __restrict__ in, int in_ld,
                                                        float* __restrict__ out, int out_ld, int N, int H, int W, int C,
-                                                       int accumulate) {
+                                                       int accumulate, PixDecode dec) {
   const int G = C >> 2;
-  const size_t total = (size_t)N * H * W * G;
-  for (size_t i = xcd_block_id() * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-    const int g = (int)(i % G);
-    size_t pix = i / G;
-    const int x = (int)(pix % W);
-    pix /= W;
-    const int y = (int)(pix % H), n = (int)(pix / H);
+  const uint32_t total = (uint32_t)N * H * W * G;
+  for (uint32_t i = xcd_block_id() * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+    int g, x, y, n;
+    uint32_t opix;
+    pix_decode(dec, i, g, x, y, n, opix);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int r = -1; r <= 1; ++r)
@@ -176,7 +172,7 @@ __global__ __launch_bounds__(256) void avgpool3_kernel(const float* __restrict__
       }
     const float k = 1.f / 9.f;
     acc.x *= k; acc.y *= k; acc.z *= k; acc.w *= k;
-    float4* o = reinterpret_cast<float4*>(out + ((size_t)(n * H + y) * W + x) * out_ld + g * 4);
+    float4* o = reinterpret_cast<float4*>(out + (size_t)opix * out_ld + g * 4);
     if (accumulate) {
       const float4 prev = *o;
       acc.x += prev.x; acc.y += prev.y; acc.z += prev.z; acc.w += prev.w;
@@ -188,8 +184,9 @@ __global__ __launch_bounds__(256) void avgpool3_kernel(const float* __restrict__
 int tbn_launch_avgpool3_fwd(const float* in, int in_ld, float* out, int out_ld, int N, int H, int W, int C,
                             int accumulate, hipStream_t st) {
   TBN_REQUIRE(C % 4 == 0 && in_ld % 4 == 0 && out_ld % 4 == 0, "avgpool: C / pitches must be multiples of 4");
+  TBN_REQUIRE((size_t)N * H * W * (C / 4) < (1ull << 31), "avgpool: too many elements per call");
   hipLaunchKernelGGL(avgpool3_kernel, dim3(ew_grid((size_t)N * H * W * C / 4)), dim3(256), 0, st, in, in_ld, out,
-                     out_ld, N, H, W, C, accumulate);
+                     out_ld, N, H, W, C, accumulate, make_pixdecode(C / 4, W, H));
   TBN_CHECK_LAUNCH("avgpool3");
   return TBN_OK;
 }

@@ -54,6 +54,29 @@ __device__ __forceinline__ uint32_t fdiv(uint32_t m, FastDiv f) {
   return (uint32_t)(((uint64_t)m * f.mul) >> (31 + f.sh));
 }
 
+// flat element index -> (float4 channel quad g, x, y, n) of an (N, H, W, G) tensor with three exact magic-number
+// divisions (~12 VALU instructions; the 64-bit `%` / `/` chains the elementwise kernels used before cost ~100 -- VALU
+// time the fp32 MFMAs running beside these HBM-bound kernels do not get).  Requires N*H*W*G < 2^31.
+struct PixDecode {
+  FastDiv g, w, h;
+};
+static inline PixDecode make_pixdecode(int G, int W, int H) {
+  PixDecode d;
+  d.g = make_fastdiv((uint32_t)G);
+  d.w = make_fastdiv((uint32_t)W);
+  d.h = make_fastdiv((uint32_t)H);
+  return d;
+}
+__device__ __forceinline__ void pix_decode(const PixDecode& d, uint32_t i, int& g, int& x, int& y, int& n, uint32_t& pix) {
+  pix = fdiv(i, d.g);
+  g = (int)(i - pix * d.g.d);
+  const uint32_t row = fdiv(pix, d.w);
+  x = (int)(pix - row * d.w.d);
+  const uint32_t nn = fdiv(row, d.h);
+  y = (int)(row - nn * d.h.d);
+  n = (int)nn;
+}
+
 // up to 3 destination column ranges of a conv / bn output (concat-slice writes)
 struct Seg {
   float* ptr;     // base of column `col_begin`
