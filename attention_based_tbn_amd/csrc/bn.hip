@@ -400,6 +400,161 @@ static PoolGrad make_poolgrad(const float* dout, int dout_ld, const unsigned cha
   return q;
 }
 
+// ---------------------------------------------------------------- fused-pool backward on 2x2 input blocks
+// 3x3 / stride 2 / pad 0 (the stem pools: the only fused ones).  pooled_grad() above evaluates four candidate windows
+// for every input pixel; taken as a 2x2 block (even-even, even-odd, odd-even, odd-odd pixel) the four pixels share the
+// SAME four windows -- (by, bx), (by, bx-1), (by-1, bx), (by-1, bx-1) -- and only 9 (pixel, window) pairs exist:
+// one arg-max word + one gradient quad per window are loaded once per block instead of four per pixel (4x fewer
+// loads, ~2x fewer VALU instructions on the two largest tensors of the network).  Same per-pixel summation order.
+struct PoolBlk {
+  const float* dout;
+  const unsigned char* argmax;
+  int dout_ld, H, W, OH, OW, C, BH, BW;
+  FastDiv div_bw, div_bh;
+};
+static PoolBlk make_poolblk(const float* dout, int dout_ld, const unsigned char* argmax, int H, int W, int OH, int OW, int C) {
+  PoolBlk q;
+  q.dout = dout; q.argmax = argmax; q.dout_ld = dout_ld;
+  q.H = H; q.W = W; q.OH = OH; q.OW = OW; q.C = C;
+  q.BH = (H + 1) / 2; q.BW = (W + 1) / 2;
+  q.div_bw = make_fastdiv((uint32_t)q.BW);
+  q.div_bh = make_fastdiv((uint32_t)q.BH);
+  return q;
+}
+// g[0] = d z(2by, 2bx), g[1] = d z(2by, 2bx+1), g[2] = d z(2by+1, 2bx), g[3] = d z(2by+1, 2bx+1)
+__device__ __forceinline__ void pooled_grad_2x2(const PoolBlk& q, int n, int by, int bx, int c, float4 (&g)[4]) {
+  const bool vy[2] = {by < q.OH, by >= 1 && by - 1 < q.OH}, vx[2] = {bx < q.OW, bx >= 1 && bx - 1 < q.OW};
+  const int oy[2] = {vy[0] ? by : 0, vy[1] ? by - 1 : 0}, ox[2] = {vx[0] ? bx : 0, vx[1] ? bx - 1 : 0};
+  uint32_t am[4];
+  float4 d[4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const size_t opix = (size_t)(n * q.OH + oy[a]) * q.OW + ox[b];
+      am[a * 2 + b] = *reinterpret_cast<const uint32_t*>(q.argmax + opix * q.C + c);
+      d[a * 2 + b] = *reinterpret_cast<const float4*>(q.dout + opix * q.dout_ld + c);
+      if (!(vy[a] && vx[b])) am[a * 2 + b] = 0xffffffffu;   // matches no tap
+    }
+  auto take = [&](float4& acc, int w, uint32_t k) {
+    const uint32_t m = am[w];
+    if ((m & 0xff) == k) acc.x += d[w].x;
+    if (((m >> 8) & 0xff) == k) acc.y += d[w].y;
+    if (((m >> 16) & 0xff) == k) acc.z += d[w].z;
+    if ((m >> 24) == k) acc.w += d[w].w;
+  };
+#pragma unroll
+  for (int i = 0; i < 4; ++i) g[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  // window index w = a*2 + b: a = 0 window row by, 1 row by-1; b = 0 window column bx, 1 column bx-1
+  take(g[0], 0, 0); take(g[0], 1, 2); take(g[0], 2, 6); take(g[0], 3, 8);   // even-even pixel: taps (0,0) (0,2) (2,0) (2,2)
+  take(g[1], 0, 1); take(g[1], 2, 7);                                       // even row, odd column: (0,1) (2,1)
+  take(g[2], 0, 3); take(g[2], 1, 5);                                       // odd row, even column: (1,0) (1,2)
+  take(g[3], 0, 4);                                                         // odd-odd: (1,1)
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_reduce_pooled2x2_kernel(PoolBlk pb, const float* __restrict__ y, int NQ,
+                                                                       int C, int qch, const float* __restrict__ scale,
+                                                                       const float* __restrict__ shift,
+                                                                       const float* __restrict__ mean,
+                                                                       const float* __restrict__ rstd,
+                                                                       float* __restrict__ partial) {
+  __shared__ float red[2 * 2048];
+  const int G = C >> 2, RP = 256 / G;
+  const int tid = threadIdx.x, cg = tid % G, rs = tid / G, c = cg * 4;
+  const int q0 = blockIdx.x * qch, q1 = min(NQ, q0 + qch);
+  float4 s1 = make_float4(0, 0, 0, 0), s2 = s1;
+  if (rs < RP) {
+    const float4 sc = *reinterpret_cast<const float4*>(scale + c);
+    const float4 sh = *reinterpret_cast<const float4*>(shift + c);
+    const float4 mu = *reinterpret_cast<const float4*>(mean + c);
+    const float4 rs4 = *reinterpret_cast<const float4*>(rstd + c);
+    for (int q = q0 + rs; q < q1; q += RP) {
+      const uint32_t row = fdiv((uint32_t)q, pb.div_bw);       // n*BH + by
+      const int bx = q - (int)row * pb.BW;
+      const uint32_t n = fdiv(row, pb.div_bh);
+      const int by = (int)row - (int)n * pb.BH;
+      float4 g[4];
+      pooled_grad_2x2(pb, (int)n, by, bx, c, g);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int iy = 2 * by + (i >> 1), ix = 2 * bx + (i & 1);
+        if (iy < pb.H && ix < pb.W) {
+          const float4 v = *reinterpret_cast<const float4*>(y + ((size_t)((int)n * pb.H + iy) * pb.W + ix) * C + c);
+          const float gx = fmaf(v.x, sc.x, sh.x) > 0.f ? g[i].x : 0.f;
+          const float gy = fmaf(v.y, sc.y, sh.y) > 0.f ? g[i].y : 0.f;
+          const float gz = fmaf(v.z, sc.z, sh.z) > 0.f ? g[i].z : 0.f;
+          const float gw = fmaf(v.w, sc.w, sh.w) > 0.f ? g[i].w : 0.f;
+          s1.x += gx; s1.y += gy; s1.z += gz; s1.w += gw;
+          s2.x = fmaf(gx, (v.x - mu.x) * rs4.x, s2.x);
+          s2.y = fmaf(gy, (v.y - mu.y) * rs4.y, s2.y);
+          s2.z = fmaf(gz, (v.z - mu.z) * rs4.z, s2.z);
+          s2.w = fmaf(gw, (v.w - mu.w) * rs4.w, s2.w);
+        }
+      }
+    }
+    *reinterpret_cast<float4*>(&red[(rs * G + cg) * 4]) = s1;
+    *reinterpret_cast<float4*>(&red[2048 + (rs * G + cg) * 4]) = s2;
+  }
+  __syncthreads();
+  for (int cc = tid; cc < C; cc += 256) {
+    float a = 0.f, b = 0.f;
+    for (int r = 0; r < RP; ++r) {
+      a += red[r * C + cc];
+      b += red[2048 + r * C + cc];
+    }
+    partial[((size_t)blockIdx.x * 2 + 0) * C + cc] = a;
+    partial[((size_t)blockIdx.x * 2 + 1) * C + cc] = b;
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_pooled2x2_kernel(PoolBlk pb, const float* y, int NQ, int C,
+                                                                      const float* __restrict__ scale,
+                                                                      const float* __restrict__ shift,
+                                                                      const float* __restrict__ coef, float* dy,
+                                                                      FastDiv divg) {
+  const int G = C >> 2;
+  const uint32_t total = (uint32_t)NQ * G;
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+    const uint32_t q = fdiv(i, divg);
+    const int c = (int)(i - q * (uint32_t)G) * 4;
+    const uint32_t row = fdiv(q, pb.div_bw);
+    const int bx = (int)q - (int)row * pb.BW;
+    const uint32_t n = fdiv(row, pb.div_bh);
+    const int by = (int)row - (int)n * pb.BH;
+    float4 g[4];
+    pooled_grad_2x2(pb, (int)n, by, bx, c, g);
+    const float4 sc = *reinterpret_cast<const float4*>(scale + c);
+    const float4 sh = *reinterpret_cast<const float4*>(shift + c);
+    const float4 ca = *reinterpret_cast<const float4*>(coef + c);
+    const float4 cb = *reinterpret_cast<const float4*>(coef + C + c);
+    const float4 cc = *reinterpret_cast<const float4*>(coef + 2 * C + c);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int iy = 2 * by + (k >> 1), ix = 2 * bx + (k & 1);
+      if (iy < pb.H && ix < pb.W) {
+        const size_t off = ((size_t)((int)n * pb.H + iy) * pb.W + ix) * C + c;
+        const float4 v = *reinterpret_cast<const float4*>(y + off);
+        float4 o;
+        o.x = fmaf(ca.x, fmaf(v.x, sc.x, sh.x) > 0.f ? g[k].x : 0.f, fmaf(cb.x, v.x, cc.x));
+        o.y = fmaf(ca.y, fmaf(v.y, sc.y, sh.y) > 0.f ? g[k].y : 0.f, fmaf(cb.y, v.y, cc.y));
+        o.z = fmaf(ca.z, fmaf(v.z, sc.z, sh.z) > 0.f ? g[k].z : 0.f, fmaf(cb.z, v.z, cc.z));
+        o.w = fmaf(ca.w, fmaf(v.w, sc.w, sh.w) > 0.f ? g[k].w : 0.f, fmaf(cb.w, v.w, cc.w));
+        *reinterpret_cast<float4*>(dy + off) = o;
+      }
+    }
+  }
+}
+
+// number of partial rows the pooled reduce writes (the engine sizes the finalize by it)
+int tbn_bn_bwd_pooled_parts(int N, int H, int W, int C, int stride, int pad) {
+  if (stride == 2 && pad == 0) {
+    const int NQ = N * ((H + 1) / 2) * ((W + 1) / 2);
+    const int rp = 256 / (C / 4);
+    return cdiv(NQ, pick_chunk(NQ, rp));
+  }
+  return tbn_bn_bwd_parts(N * H * W, C);
+}
+
 // BN-backward reduce / apply of a conv fused with its max pool: dz = gather(dpooled, argmax) on the fly
 int tbn_launch_bn_bwd_reduce_pooled(const float* dpooled, int dpooled_ld, const unsigned char* argmax, int N, int H,
                                     int W, int OH, int OW, int stride, int pad, const float* y, int C,
@@ -407,6 +562,15 @@ int tbn_launch_bn_bwd_reduce_pooled(const float* dpooled, int dpooled_ld, const 
                                     float* partial, hipStream_t st) {
   TBN_REQUIRE(C % 4 == 0 && C <= 1024 && dpooled_ld % 4 == 0, "bn_bwd_reduce_pooled: bad C / pitch");
   TBN_REQUIRE((long)N * H * W < (1l << 31), "bn_bwd_reduce_pooled: too many pixels");
+  if (stride == 2 && pad == 0) {
+    const int NQ = N * ((H + 1) / 2) * ((W + 1) / 2);
+    const int rp = 256 / (C / 4), qch = pick_chunk(NQ, rp), parts = cdiv(NQ, qch);
+    hipLaunchKernelGGL(bn_bwd_reduce_pooled2x2_kernel, dim3(parts), dim3(256), 0, st,
+                       make_poolblk(dpooled, dpooled_ld, argmax, H, W, OH, OW, C), y, NQ, C, qch, scale, shift, mean, rstd,
+                       partial);
+    TBN_CHECK_LAUNCH("bn_bwd_reduce_pooled2x2");
+    return TBN_OK;
+  }
   const int P = N * H * W;
   CSeg3 s3 = {};
   s3.n = 1;
@@ -498,6 +662,15 @@ int tbn_launch_bn_bwd_apply_pooled(const float* dpooled, int dpooled_ld, const u
                                    int OH, int OW, int stride, int pad, const float* y, int C, const float* scale,
                                    const float* shift, const float* coef, float* dy, hipStream_t st) {
   TBN_REQUIRE(C % 4 == 0 && dpooled_ld % 4 == 0, "bn_bwd_apply_pooled: bad C / pitch");
+  if (stride == 2 && pad == 0) {
+    const int NQ = N * ((H + 1) / 2) * ((W + 1) / 2);
+    TBN_REQUIRE((size_t)NQ * (C / 4) < (1ull << 31), "bn_bwd_apply_pooled: too many elements per call");
+    hipLaunchKernelGGL(bn_bwd_apply_pooled2x2_kernel, dim3(ew_grid((size_t)NQ * C / 4)), dim3(256), 0, st,
+                       make_poolblk(dpooled, dpooled_ld, argmax, H, W, OH, OW, C), y, NQ, C, scale, shift, coef, dy,
+                       make_fastdiv((uint32_t)(C / 4)));
+    TBN_CHECK_LAUNCH("bn_bwd_apply_pooled2x2");
+    return TBN_OK;
+  }
   const int P = N * H * W;
   CSeg3 s3 = {};
   s3.n = 1;

@@ -1316,7 +1316,8 @@ int tbn_backbone_backward(const tbn_backbone_plan* P, const float* dfeatures, co
           TBN_TRY(tbn_launch_bn_bwd_reduce_pooled(dpool, ob.C, am, R, c0.outH, c0.outW, ob.H, ob.W, pl.stride, pl.pad, y,
                                                   q.cout, scale + q.c_off, shift + q.c_off, mean + q.c_off,
                                                   rstd + q.c_off, partial, st));
-          TBN_TRY(tbn_launch_bn_bwd_finalize(partial, tbn_bn_bwd_parts(M, q.cout), M, q.cout, scale + q.c_off,
+          TBN_TRY(tbn_launch_bn_bwd_finalize(partial, tbn_bn_bwd_pooled_parts(R, c0.outH, c0.outW, q.cout, pl.stride, pl.pad), M,
+                                             q.cout, scale + q.c_off,
                                              mean + q.c_off, rstd + q.c_off, coef, bn_grad ? g->dgamma + q.c_off : nullptr,
                                              bn_grad ? g->dbeta + q.c_off : nullptr, g->dbias + q.c_off, st));
           TBN_TRY(tbn_launch_bn_bwd_apply_pooled(dpool, ob.C, am, R, c0.outH, c0.outW, ob.H, ob.W, pl.stride, pl.pad, y,

@@ -129,6 +129,7 @@ int tbn_launch_bn_bwd_reduce_pooled(const float* dpooled, int dpooled_ld, const 
                                     int W, int OH, int OW, int stride, int pad, const float* y, int C,
                                     const float* scale, const float* shift, const float* mean, const float* rstd,
                                     float* partial, hipStream_t st);
+int tbn_bn_bwd_pooled_parts(int N, int H, int W, int C, int stride, int pad);   // partial rows of the pooled reduce
 int tbn_launch_bn_bwd_apply_pooled(const float* dpooled, int dpooled_ld, const unsigned char* argmax, int N, int H, int W,
                                    int OH, int OW, int stride, int pad, const float* y, int C, const float* scale,
                                    const float* shift, const float* coef, float* dy, hipStream_t st);
