@@ -9,6 +9,7 @@
 // ATen) so the backward is a deterministic gather (no float atomics).
 #include "tbn_common.h"
 #include "tbn_kernels.h"
+#include "tbn_pool_dev.h"
 
 static inline int ew_grid(size_t items) {
   size_t g = (items + 255) / 256;
@@ -139,10 +140,49 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
   }
 }
 
+// 3x3 / stride 2 / pad 0 (pool1, pool2 when not fused, the pass-through pools of inception_3c / 4e): a thread owns a
+// 2x2 input block, whose four pixels share the same four windows (tbn_pool_dev.h)
+__global__ __launch_bounds__(256) void maxpool_bwd2x2_kernel(PoolBlk pb, float* __restrict__ din, int din_ld, int NQ,
+                                                             int C, int accumulate, FastDiv divg) {
+  const int G = C >> 2;
+  const uint32_t total = (uint32_t)NQ * G;
+  for (uint32_t i = xcd_block_id() * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+    const uint32_t q = fdiv(i, divg);
+    const int c = (int)(i - q * (uint32_t)G) * 4;
+    const uint32_t row = fdiv(q, pb.div_bw);
+    const int bx = (int)q - (int)row * pb.BW;
+    const uint32_t n = fdiv(row, pb.div_bh);
+    const int by = (int)row - (int)n * pb.BH;
+    float4 g[4];
+    pooled_grad_2x2(pb, (int)n, by, bx, c, g);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int iy = 2 * by + (k >> 1), ix = 2 * bx + (k & 1);
+      if (iy < pb.H && ix < pb.W) {
+        float4* o = reinterpret_cast<float4*>(din + ((size_t)((int)n * pb.H + iy) * pb.W + ix) * din_ld + c);
+        float4 acc = g[k];
+        if (accumulate) {
+          const float4 prev = *o;
+          acc.x += prev.x; acc.y += prev.y; acc.z += prev.z; acc.w += prev.w;
+        }
+        *o = acc;
+      }
+    }
+  }
+}
+
 int tbn_launch_maxpool_bwd(const float* dout, int dout_ld, const uint8_t* argmax, float* din, int din_ld, int N,
                            int H, int W, int C, int OH, int OW, int stride, int pad, int accumulate, hipStream_t st) {
   TBN_REQUIRE(C % 4 == 0 && din_ld % 4 == 0 && dout_ld % 4 == 0, "maxpool_bwd: C / pitches must be multiples of 4");
   TBN_REQUIRE((size_t)N * H * W * (C / 4) < (1ull << 31), "maxpool_bwd: too many elements per call");
+  if (stride == 2 && pad == 0) {
+    const int NQ = N * ((H + 1) / 2) * ((W + 1) / 2);
+    hipLaunchKernelGGL(maxpool_bwd2x2_kernel, dim3(ew_grid((size_t)NQ * C / 4)), dim3(256), 0, st,
+                       make_poolblk(dout, dout_ld, argmax, H, W, OH, OW, C), din, din_ld, NQ, C, accumulate,
+                       make_fastdiv((uint32_t)(C / 4)));
+    TBN_CHECK_LAUNCH("maxpool_bwd2x2");
+    return TBN_OK;
+  }
   hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(ew_grid((size_t)N * H * W * C / 4)), dim3(256), 0, st, dout, dout_ld,
                      argmax, din, din_ld, N, H, W, C, OH, OW, stride, pad, accumulate, make_pixdecode(C / 4, W, H));
   TBN_CHECK_LAUNCH("maxpool_bwd");
