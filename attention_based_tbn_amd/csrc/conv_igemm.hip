@@ -18,8 +18,10 @@
 //   sum / sum-of-squares partials for training-mode BatchNorm | eval BN folded scale/shift + ReLU.
 // The same kernel is the data-gradient: dgrad = conv of dy with tap-flipped, channel-transposed
 //   weights (`up` = forward stride handles strided layers by zero-insertion on the fly).
-// ROWMODE is the 7x7 stem: input is NHWC padded to `cp` channels, a filter row (7*cp floats,
-//   padded to a multiple of 32) is one contiguous K run.
+// ROWMODE is the 7x7 / stride 2 stem as a 4x4 / stride 1 conv on the 2x2 space-to-depth image (pool.hip): the K of an
+//   output pixel is R contiguous runs of `Cin` floats (4 s2d pixels x 4*cin channels), one per s2d row, packed back to
+//   back -- 32-float K chunks straddle runs -- and the image carries its zero border physically, so the loads need
+//   no masks at all.
 #include <cstdio>
 #include <cstdlib>
 #include <type_traits>
@@ -252,33 +254,30 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& p, const int bid, f
   const i32x4 wt_rsrc = make_rsrc(p.wt, p.wt_bytes);
 
   const int c4 = tid & 7, r0 = tid >> 3;
-  unsigned a_off[AR];   // byte offset of the row's (n, iy0, ix0) pixel (wraps for negative ix0 in ROWMODE)
-  unsigned a_mask[AR];  // bit t: tap t of this row lies inside the image (ROWMODE: bit r = filter row)
-  int a_ix[AR];         // ROWMODE: first input column of the row's window
+  unsigned a_off[AR];   // byte offset of the row's (n, iy0, ix0) pixel (ROWMODE: out of range for rows >= M)
+  unsigned a_mask[AR];  // bit t: tap t of this row lies inside the image (unused in ROWMODE: the border is physical)
   {
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
       const int m = m0 + r0 + 32 * i;
       unsigned mask = 0;
-      int off = 0, ix0 = 0;
+      unsigned off = ROWMODE ? TBN_OOB : 0u;
       if (m < p.M) {
         const uint32_t n = fdiv((uint32_t)m, p.div_ohw);
         const uint32_t rem = (uint32_t)m - n * p.div_ohw.d;
         const uint32_t a = fdiv(rem, p.div_ow);
         const uint32_t b = rem - a * p.div_ow.d;
         const int iy0 = (int)a * p.in_sy;
-        ix0 = (int)b * p.in_sx;
-        // taps form a (tny x tnx) grid starting at (ty0, tx0): validity = row bits x column bits
-        unsigned yb = 0, xb = 0;
-#pragma unroll
-        for (int r = 0; r < 7; ++r)
-          if (r < p.tny && (unsigned)(iy0 + p.ty0 + r) < (unsigned)p.H) yb |= 1u << r;
+        const int ix0 = (int)b * p.in_sx;
         if (ROWMODE) {
-          ix0 -= p.pad;
-          off = (((int)n * p.H + iy0) * p.W + ix0) * p.cp * 4;
-          mask = yb;
+          off = (unsigned)((((int)n * p.H + iy0) * p.W + ix0) * p.cp * 4);
         } else {
-          off = (((int)n * p.H + iy0) * p.W + ix0) * p.in_ld * 4;
+          // taps form a (tny x tnx) grid starting at (ty0, tx0): validity = row bits x column bits
+          unsigned yb = 0, xb = 0;
+#pragma unroll
+          for (int r = 0; r < 3; ++r)
+            if (r < p.tny && (unsigned)(iy0 + p.ty0 + r) < (unsigned)p.H) yb |= 1u << r;
+          off = (unsigned)((((int)n * p.H + iy0) * p.W + ix0) * p.in_ld * 4);
 #pragma unroll
           for (int c = 0; c < 3; ++c)
             if (c < p.tnx && (unsigned)(ix0 + p.tx0 + c) < (unsigned)p.W) xb |= 1u << c;
@@ -287,14 +286,13 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& p, const int bid, f
             if ((yb >> r) & 1u) mask |= xb << (r * p.tnx);
         }
       }
-      a_off[i] = (unsigned)off;
+      a_off[i] = off;
       a_mask[i] = mask;
-      a_ix[i] = ix0;
     }
   }
 
   if (ABL(128)) {  // ablation: exit after the per-row setup
-    if (a_off[0] == 0x12345u && a_mask[AR - 1] == 77u) p.seg[0].ptr[0] = (float)a_ix[0];
+    if (a_off[0] == 0x12345u && a_mask[AR - 1] == 77u) p.seg[0].ptr[0] = 1.f;
     return;
   }
   f32x16 acc[MT][NT];
@@ -318,6 +316,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& p, const int bid, f
   unsigned b_voff[NT];
 #pragma unroll
   for (int i = 0; i < NT; ++i) b_voff[i] = b_row + (unsigned)(32 * i) * (unsigned)p.Krow * 4u;
+  const unsigned rm_pitch = (unsigned)(p.W * p.cp) * 4u;   // ROWMODE: bytes between the runs of a pixel (one image row)
   auto load_tiles = [&]() {
     if (!ROWMODE) {
       if (l_c0 == 0) {
@@ -329,21 +328,20 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& p, const int bid, f
 #pragma unroll
       for (int i = 0; i < AR; ++i) ra[i] = buf_load4(in_rsrc, a_cur[i], soff);
     } else {
-      const int cc = l_c0 + c4 * 4;
-      const unsigned toff = l_toff + (unsigned)cc * 4u;
-      const int dpx = cc / p.cp;
+      // l_c0 counts the packed K floats: this lane's float4 sits in run t at float4 w4 (one division per K-step,
+      // shared by the thread's AR rows; no masks -- the zero border is in the image)
+      const uint32_t f = ((uint32_t)l_c0 >> 2) + (uint32_t)c4;
+      const uint32_t t = fdiv(f, p.div_rl4);
+      const unsigned roff = t * rm_pitch + (f - t * p.div_rl4.d) * 16u;
 #pragma unroll
-      for (int i = 0; i < AR; ++i) {
-        const bool ok = ((a_mask[i] >> l_tap) & 1u) && ((unsigned)(a_ix[i] + dpx) < (unsigned)p.W);
-        ra[i] = buf_load4(in_rsrc, ok ? a_off[i] + toff : TBN_OOB);
-      }
+      for (int i = 0; i < AR; ++i) ra[i] = buf_load4(in_rsrc, a_off[i] + roff);   // rows >= M: 2^31 + roff stays out of range
     }
     const unsigned koff = l_koff + (unsigned)l_c0 * 4u;
 #pragma unroll
     for (int i = 0; i < NT; ++i)  // rows >= Cout are beyond wt_bytes -> zeros
       rb[i] = buf_load4(wt_rsrc, b_voff[i], koff);
     l_c0 += 32;
-    if (l_c0 == p.Cin) {
+    if (!ROWMODE && l_c0 == p.Cin) {
       l_c0 = 0;
       ++l_tap;
       if (l_tap < p.ntaps) {
@@ -881,6 +879,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
   const bool a_full = (co0 + 32 * MT <= p.Cout), b_full = (ci0 + 32 * NT <= p.Cin);
   const i32x4 dy_rsrc = make_rsrc(p.dy, p.dy_bytes);
   const i32x4 x_rsrc = make_rsrc(p.x, p.x_bytes);
+  // ROWMODE (the stem, see conv_igemm_body): the `Cin` columns are the packed K of a pixel -- R runs of `rl` floats,
+  // one per row of the zero-padded space-to-depth image.  A lane's columns are fixed: their (run, offset) byte
+  // displacements from the pixel's first run are computed once; the loop only decodes the pixel.
+  unsigned rm_off[BI];
+  if (ROWMODE) {
+#pragma unroll
+    for (int k = 0; k < BI; ++k) {
+      const int cc = ci0 + lq * 4 + 16 * k;
+      const uint32_t f = (uint32_t)cc >> 2, t = fdiv(f, p.div_rl4);
+      rm_off[k] = (t * (uint32_t)(p.W * p.cp) + (f - t * p.div_rl4.d) * 4u) * 4u;
+    }
+  }
   auto load_tiles = [&](int row0) {
     const int m = row0 + lrow16;
     const bool row_ok = m < pend;
@@ -908,13 +918,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
         rb[k] = buf_load4(x_rsrc, ok ? base + 64u * k : TBN_OOB);
       }
     } else {
-      const bool okrow = row_ok && ((unsigned)iy < (unsigned)p.H);
+      // no masks: the border is in the image; a row >= pend starts at 2^31 and stays out of range -> zeros
+      const unsigned base = row_ok ? ((n * p.H + iy) * p.W + ix) * (unsigned)p.cp * 4u : TBN_OOB;
 #pragma unroll
       for (int k = 0; k < BI; ++k) {
-        const int cc = ci0 + lq * 4 + 16 * k;
-        const bool ok = okrow && (cc < p.Cin) && ((unsigned)(ix + cc / p.cp) < (unsigned)p.W);
-        const unsigned off = (unsigned)((int)(((n * p.H + iy) * p.W) * (unsigned)p.cp) + ix * p.cp + cc) * 4u;
-        rb[k] = buf_load4(x_rsrc, ok ? off : TBN_OOB);
+        const bool ok = b_full || (ci0 + lq * 4 + 16 * k < p.Cin);
+        rb[k] = buf_load4(x_rsrc, ok ? base + rm_off[k] : TBN_OOB);
       }
     }
   };
@@ -1237,8 +1246,18 @@ static int launch_conv_tiles(ConvP& p, int rowmode, int mt, int nt, hipStream_t 
 // validation + derived fields common to every launch form; `*single` = 1 when the launch is a single GEMM
 // (up == 1: geometry completely filled), 0 when the caller still has to split it into parity phases (up == 2)
 static int conv_prepare(ConvP& p, int rowmode, int* single) {
-  TBN_REQUIRE(p.K % 32 == 0 && p.Cin % 32 == 0, "conv: K (%d) and per-tap Cin (%d) must be multiples of 32", p.K,
-              p.Cin);
+  if (rowmode) {
+    // R contiguous runs of Cin floats per output pixel, read from a physically zero-padded image without masks
+    p.K = p.R * p.Cin;
+    TBN_REQUIRE(p.K % 32 == 0 && p.Cin % 4 == 0 && p.cp % 4 == 0 && p.Cin % p.cp == 0 && p.pad == 0 && p.up == 1,
+                "conv: packed-row mode needs K = R*Cin (%d) % 32 == 0, Cin / cp multiples of 4, pad 0", p.K);
+    TBN_REQUIRE((p.OH - 1) * p.stride + p.R <= p.H && (p.OW - 1) * p.stride + p.Cin / p.cp <= p.W,
+                "conv: packed-row mode reads beyond the padded image (%dx%d)", p.H, p.W);
+  } else {
+    TBN_REQUIRE(p.K % 32 == 0 && p.Cin % 32 == 0, "conv: K (%d) and per-tap Cin (%d) must be multiples of 32", p.K,
+                p.Cin);
+    TBN_REQUIRE(p.R <= 3 && p.S <= 3, "conv: filters larger than 3x3 take the packed-row (stem) path");
+  }
   TBN_REQUIRE(p.in_ld % 4 == 0 && p.nseg >= 1 && p.nseg <= TBN_CONV_MAXSEG, "conv: bad in_ld %d / nseg %d", p.in_ld,
               p.nseg);
   TBN_REQUIRE(p.nred >= 0 && p.nred <= TBN_CONV_MAXSEG && (p.nred == 0 || (p.mode == CONV_EPI_PLAIN && !rowmode)),
@@ -1270,11 +1289,12 @@ static int conv_prepare(ConvP& p, int rowmode, int* single) {
                 i, p.seg[i].col_begin);
     p.seg_bytes[i] = (unsigned)ob;
   }
-  const int taps_full = rowmode ? p.R : p.R * p.S;
-  p.Krow = taps_full * p.Cin;
+  const int taps_full = rowmode ? 1 : p.R * p.S;
+  p.Krow = rowmode ? p.K : taps_full * p.Cin;
   p.wt_bytes = (unsigned)((size_t)p.Cout * p.Krow * sizeof(float));
+  p.div_rl4 = make_fastdiv((uint32_t)(rowmode ? p.Cin / 4 : 1));
   if (p.up == 1) {
-    TBN_REQUIRE(taps_full <= 9, "conv: at most 9 taps (3x3) on the generic path, 7 filter rows on the stem path");
+    TBN_REQUIRE(taps_full <= 9, "conv: at most 9 taps (3x3)");
     p.OHs = p.OH;
     p.OWs = p.OW;
     p.out_sy = p.out_sx = 1;
@@ -1282,15 +1302,15 @@ static int conv_prepare(ConvP& p, int rowmode, int* single) {
     p.in_sy = p.in_sx = p.stride;
     p.ntaps = taps_full;
     for (int t = 0; t < taps_full; ++t) {
-      const int r = rowmode ? t : t / p.S, s = rowmode ? 0 : t % p.S;
+      const int r = rowmode ? 0 : t / p.S, s = rowmode ? 0 : t % p.S;
       p.tap_dy[t] = r - p.pad;
-      p.tap_dx[t] = rowmode ? 0 : s - p.pad;
+      p.tap_dx[t] = s - p.pad;
       p.tap_koff[t] = t * p.Cin;
-      p.tap_off[t] = rowmode ? p.tap_dy[t] * p.W * p.cp * 4 : (p.tap_dy[t] * p.W + p.tap_dx[t]) * p.in_ld * 4;
+      p.tap_off[t] = rowmode ? 0 : (p.tap_dy[t] * p.W + p.tap_dx[t]) * p.in_ld * 4;
     }
-    p.K = p.ntaps * p.Cin;
+    if (!rowmode) p.K = p.ntaps * p.Cin;
     p.ty0 = -p.pad;
-    p.tny = p.R;
+    p.tny = rowmode ? 1 : p.R;
     p.tx0 = -p.pad;
     p.tnx = rowmode ? 1 : p.S;
     p.div_ohw = make_fastdiv((uint32_t)(p.OHs * p.OWs));
@@ -1601,6 +1621,13 @@ int tbn_launch_wgrad(WgradP p, int rowmode, float* dw, float* workspace, hipStre
   if (const char* e = getenv("TBN_WGRAD_MT")) p.mt = atoi(e);
   if (const char* e = getenv("TBN_WGRAD_NT")) p.nt = atoi(e);
 #endif
+  if (rowmode) {
+    TBN_REQUIRE(p.taps == 1 && p.pad == 0 && p.rl > 0 && p.rl % 4 == 0 && p.cp % 4 == 0 && p.rl % p.cp == 0 && p.Cin % p.rl == 0,
+                "wgrad: packed-row mode needs taps 1, pad 0, Cin = R * rl, rl / cp multiples of 4");
+    TBN_REQUIRE((p.OH - 1) * p.stride + p.Cin / p.rl <= p.H && (p.OW - 1) * p.stride + p.rl / p.cp <= p.W,
+                "wgrad: packed-row mode reads beyond the padded image (%dx%d)", p.H, p.W);
+  }
+  p.div_rl4 = make_fastdiv((uint32_t)(rowmode ? p.rl / 4 : 1));
   int mt = p.mt, nt = p.nt, splits, rps;   // 0: heuristic tile
   tbn_wgrad_plan(p.M, p.Cout, p.Cin, p.taps, &mt, &nt, &splits, &rps);
   p.K = p.taps * p.Cin;

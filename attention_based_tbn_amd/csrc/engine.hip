@@ -122,10 +122,9 @@ int pool_out(int in, int k, int stride, int pad, bool ceil_mode) {
 
 struct tbn_backbone_plan {
   int cin0, frames, H, W;
-  int cp, kw;  // stem channel padding / padded filter-row length
-  // stem conv as executed: 7 filter rows / stride 2 / pad 3 on the (H, W, cp) image, or -- one input channel, even
-  // H and W -- 4 rows / stride 1 / pad 2 on the 2x2 space-to-depth image (H/2, W/2, 4), see pool.hip
-  bool s2d;
+  // stem conv as executed: 4 rows / stride 1 of the zero-bordered 2x2 space-to-depth image (stem_H, stem_W, cp = 4*cin0),
+  // a filter row = kw = 4 pixels * cp contiguous floats, K = 4 * kw packed (pool.hip, conv_igemm.hip ROWMODE)
+  int cp, kw;
   int stem_rows, stem_stride, stem_pad, stem_H, stem_W;
   std::vector<Buf> bufs;
   std::vector<Conv> convs;
@@ -241,17 +240,15 @@ void add_bn_conv(tbn_backbone_plan* P, int ci) {
 // ceil-mode pass-through max pool raises)
 bool build_graph(tbn_backbone_plan* P) {
   const int cin0 = P->cin0;
-  P->cp = (cin0 + 3) / 4 * 4;
-  P->kw = (7 * P->cp + 31) / 32 * 32;
-  P->s2d = cin0 == 1 && P->H % 2 == 0 && P->W % 2 == 0;
-  P->stem_rows = P->s2d ? 4 : 7;
-  P->stem_stride = P->s2d ? 1 : 2;
-  P->stem_pad = P->s2d ? 2 : 3;
-  P->stem_H = P->s2d ? P->H / 2 : P->H;
-  P->stem_W = P->s2d ? P->W / 2 : P->W;
-  if (P->s2d) P->kw = 32;   // 4 pixels x 4 parities = 16 real slots
+  P->cp = 4 * cin0;
+  P->kw = 4 * P->cp;
+  P->stem_rows = 4;
+  P->stem_stride = 1;
+  P->stem_pad = 0;
+  P->stem_H = (P->H + 1) / 2 + 3;
+  P->stem_W = (P->W + 1) / 2 + 3;
   P->weight_floats = P->chan_floats = 0;
-  const int x0 = add_buf(P, P->H, P->W, P->cp);   // logical extent; the s2d layout has the same number of floats
+  const int x0 = add_buf(P, P->H, P->W, cin0);   // logical extent (the stored image is the bordered s2d form: plan_memory)
   // stem
   int h1 = (P->H + 6 - 7) / 2 + 1, w1 = (P->W + 6 - 7) / 2 + 1;
   const int c1 = add_buf(P, h1, w1, 64);
@@ -479,7 +476,10 @@ void plan_memory(tbn_backbone_plan* P) {
     off += (n + 63) / 64 * 64;  // 256-B aligned float regions
     return o;
   };
-  for (auto& b : P->bufs) b.off = take(R * b.H * b.W * b.C);
+  for (size_t i = 0; i < P->bufs.size(); ++i) {
+    Buf& b = P->bufs[i];
+    b.off = i == 0 ? take(R * P->stem_H * P->stem_W * P->cp) : take(R * b.H * b.W * b.C);
+  }
   P->x0_off = P->bufs[0].off;
   P->stats_off = take(4 * P->chan_floats);  // mean | rstd | scale | shift
   // per-layer tiles and scratch sizes
@@ -494,7 +494,7 @@ void plan_memory(tbn_backbone_plan* P) {
       size_t bparts = (size_t)tbn_bn_bwd_parts(M, c.parts[k].cout) * 2 * c.parts[k].cout;
       if (bparts > partial) partial = bparts;
     }
-    const int taps = c.stem ? P->stem_rows : c.k * c.k, ci = c.stem ? P->kw : c.cin;
+    const int taps = c.stem ? 1 : c.k * c.k, ci = c.stem ? P->stem_rows * P->kw : c.cin;
     size_t ws = tbn_wgrad_workspace_floats(M, c.cout, ci, taps);
     if (ws > wsplit) wsplit = ws;
     if (c.need_dgrad) {
@@ -519,7 +519,7 @@ void plan_memory(tbn_backbone_plan* P) {
   P->wsplit_floats = wsplit;
   P->wt_floats = wtf;
   P->partial_off = take(TBN_BN_MAXL * partial);   // one region per member of a batched BN step
-  P->wpack_off = take((size_t)64 * 7 * P->kw);
+  P->wpack_off = take((size_t)64 * P->stem_rows * P->kw);
   for (auto& c : P->convs)   // raw / pooled conv output of the pool-after-conv layers: needed in eval too
     for (int k = 0; k < c.nparts; ++k)
       if (c.parts[k].pooled) {
@@ -542,7 +542,7 @@ void plan_memory(tbn_backbone_plan* P) {
   P->coef_off = take(TBN_BN_MAXL * 3 * 1024);
   P->wsplit_off = take(wsplit);
   P->wt_off = take(wtf);
-  P->dwpack_off = take((size_t)64 * 7 * P->kw);
+  P->dwpack_off = take((size_t)64 * P->stem_rows * P->kw);
   size_t bytes = off * sizeof(float);
   P->argmax_bytes_off = bytes;
   for (auto& p : P->pools)
@@ -643,6 +643,7 @@ int tbn_backbone_tensor_info(const tbn_backbone_plan* P, const char* conv_name, 
       *rows = P->frames * c.outH * c.outW;
       *cols = q.cout;
       if (kind == 3) {
+        TBN_REQUIRE(!c.stem, "tensor_info: the stem reads the bordered space-to-depth image, not an NHWC buffer");
         const Buf& ib = P->bufs[c.inbuf];
         *offset = (long)ib.off;
         *rows = P->frames * c.inH * c.inW;
@@ -713,8 +714,8 @@ void fill_fwd(const tbn_backbone_plan* P, const Conv& c, float* ws, const float*
     p.R = P->stem_rows;
     p.S = 1;
     p.K = P->stem_rows * P->kw;
-    p.cp = P->cp;
-    p.H = P->stem_H;          // s2d: the 4-row / stride-1 conv on the space-to-depth image
+    p.cp = p.in_ld = P->cp;
+    p.H = P->stem_H;          // the 4-row / stride-1 conv on the bordered space-to-depth image
     p.W = P->stem_W;
     p.stride = P->stem_stride;
     p.pad = P->stem_pad;
@@ -800,11 +801,12 @@ void fill_wgrad(const tbn_backbone_plan* P, const Conv& c, float* ws, int R, Wgr
   wp->mt = c.w_mt;
   wp->nt = c.w_nt;
   if (c.stem) {
-    wp->Cin = P->kw;
+    wp->Cin = P->stem_rows * P->kw;
     wp->R = P->stem_rows;
     wp->S = 1;
-    wp->taps = P->stem_rows;
-    wp->cp = P->cp;
+    wp->taps = 1;
+    wp->cp = wp->x_ld = P->cp;
+    wp->rl = P->kw;
     wp->H = P->stem_H;
     wp->W = P->stem_W;
     wp->stride = P->stem_stride;
@@ -848,13 +850,8 @@ int tbn_backbone_forward(const tbn_backbone_plan* P, int training, const float* 
   float* shift = scale + P->chan_floats;
   float* wpack = ws + P->wpack_off;
 
-  if (P->s2d) {
-    TBN_TRY(tbn_launch_nchw1_to_s2d(x_nchw, ws + P->x0_off, R, P->H, P->W, st));
-    TBN_TRY(tbn_launch_pack_stem_weight_s2d(prm->weight + P->convs[0].w_off, wpack, 64, st));
-  } else {
-    TBN_TRY(tbn_launch_nchw_to_nhwc_pad(x_nchw, ws + P->x0_off, R, P->cin0, P->H, P->W, P->cp, st));
-    TBN_TRY(tbn_launch_pack_stem_weight(prm->weight + P->convs[0].w_off, wpack, 64, P->cin0, P->cp, P->kw, st));
-  }
+  TBN_TRY(tbn_launch_nchw_to_s2d_pad(x_nchw, ws + P->x0_off, R, P->cin0, P->H, P->W, st));
+  TBN_TRY(tbn_launch_pack_stem_weight_s2d(prm->weight + P->convs[0].w_off, wpack, 64, P->cin0, st));
   if (!training)
     TBN_TRY(tbn_launch_bn_fold(prm->gamma, prm->beta, prm->running_mean, prm->running_var, prm->bias, prm->eps, scale,
                                shift, (int)P->chan_floats, st));
@@ -1385,10 +1382,7 @@ int tbn_backbone_backward(const tbn_backbone_plan* P, const float* dfeatures, co
       if (c.stem) {
         float* dwp = ws + P->dwpack_off;
         TBN_TRY(tbn_launch_wgrad(wp, 1, dwp, ws + P->wsplit_off, wst));
-        if (P->s2d)
-          TBN_TRY(tbn_launch_unpack_stem_wgrad_s2d(dwp, g->dweight + c.w_off, 64, wst));
-        else
-          TBN_TRY(tbn_launch_unpack_stem_wgrad(dwp, g->dweight + c.w_off, 64, P->cin0, P->cp, P->kw, wst));
+        TBN_TRY(tbn_launch_unpack_stem_wgrad_s2d(dwp, g->dweight + c.w_off, 64, P->cin0, wst));
       } else {
         TBN_TRY(tbn_launch_wgrad(wp, 0, g->dweight + c.w_off, ws + P->wsplit_off, wst));
       }

@@ -306,126 +306,93 @@ int tbn_launch_spatial_mean_bwd(const float* dout, int dout_ld, float* din, int 
   return TBN_OK;
 }
 
-// NCHW (reference tensor layout, model.py:211-213) -> NHWC padded to Cp channels (zeros)
-template <int Q>  // Q = Cp / 4 float4 stores per pixel
-__global__ __launch_bounds__(256) void nchw_to_nhwc_pad_kernel(const float* __restrict__ in, float* __restrict__ out,
-                                                               int N, int C, int H, int W) {
-  const size_t hw = (size_t)H * W, total = (size_t)N * hw;
+// NCHW is the reference tensor layout (model.py:211-213)
+// ---------------------------------------------------------------- the 7x7 / stride 2 / pad 3 stem as a space-to-depth conv
+// A 7x7 / stride-2 conv on C input channels is exactly a 4x4 / stride-1 conv on the 2x2 space-to-depth image
+// (4*C channels = pixel parities (y&1, x&1) x C, half the height / width): x[2oy-3+r] with r+1 = 2a+py reads s2d row
+// oy-2+a, parity py, so the taps are a, b in 0..3 with "pad 2" on the top / left and 1 on the bottom / right
+// (a = py = 0 has no source tap: zero weight).  A filter row is then 4 s2d pixels x 4C channels = 16C CONTIGUOUS floats
+// and K = 4 rows x 16C = 64C, of which 49C carry weights: 64 / 192 / 640 multiplied columns for audio / RGB / flow
+// instead of the 224 / 224 / 672 of channel-padded NHWC filter rows (7 rows x 32-float chunks).
+// The image is written WITH its zero border ([N][OH+3][OW+3][4C], OH = ceil(H/2)), so the GEMM kernels read it without
+// any bounds logic (conv_igemm.hip ROWMODE); odd H / W just leave the missing parity zero.
+template <int CT>   // CT > 0: compile-time channel count (float4 stores); 0: runtime C, scalar stores
+__global__ __launch_bounds__(256) void nchw_to_s2d_pad_kernel(const float* __restrict__ in, float* __restrict__ out, int N,
+                                                              int Crt, int H, int W, int HP, int WP) {
+  const int C = CT > 0 ? CT : Crt;
+  const size_t total = (size_t)N * HP * WP, hw = (size_t)H * W;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-    const size_t n = i / hw, p = i - n * hw;
-    const float* src = in + n * C * hw + p;   // lanes read consecutive pixels of one plane: coalesced
-    float v[4 * Q];
+    const int X = (int)(i % WP);
+    const size_t t = i / WP;
+    const int Y = (int)(t % HP), n = (int)(t / HP);
+    const int y0 = 2 * (Y - 2), x0 = 2 * (X - 2);
+    const float* src = in + (size_t)n * C * hw;
+    bool ok[4];
+    size_t off[4];
 #pragma unroll
-    for (int c = 0; c < 4 * Q; ++c) v[c] = c < C ? src[(size_t)c * hw] : 0.f;
-    float4* o = reinterpret_cast<float4*>(out + i * (4 * Q));
-#pragma unroll
-    for (int q = 0; q < Q; ++q) o[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
-  }
-}
-
-int tbn_launch_nchw_to_nhwc_pad(const float* in, float* out, int N, int C, int H, int W, int Cp, hipStream_t st) {
-  TBN_REQUIRE(Cp >= C && Cp % 4 == 0 && Cp <= 16, "nchw_to_nhwc_pad: Cp must be >= C, a multiple of 4 and <= 16");
-  const dim3 grid(ew_grid((size_t)N * H * W));
-  switch (Cp / 4) {
-    case 1: hipLaunchKernelGGL(nchw_to_nhwc_pad_kernel<1>, grid, dim3(256), 0, st, in, out, N, C, H, W); break;
-    case 2: hipLaunchKernelGGL(nchw_to_nhwc_pad_kernel<2>, grid, dim3(256), 0, st, in, out, N, C, H, W); break;
-    case 3: hipLaunchKernelGGL(nchw_to_nhwc_pad_kernel<3>, grid, dim3(256), 0, st, in, out, N, C, H, W); break;
-    default: hipLaunchKernelGGL(nchw_to_nhwc_pad_kernel<4>, grid, dim3(256), 0, st, in, out, N, C, H, W); break;
-  }
-  TBN_CHECK_LAUNCH("nchw_to_nhwc_pad");
-  return TBN_OK;
-}
-
-// stem weights [Cout][7][7][Cin] -> [Cout][7][KW]: filter row = 7*Cp floats (channel-padded), zero tail
-__global__ void pack_stem_weight_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin, int Cp,
-                                        int KW) {
-  const int total = Cout * 7 * KW;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-    const int k = i % KW, r = (i / KW) % 7, co = i / (KW * 7);
-    const int s = k / Cp, c = k - s * Cp;
-    wp[i] = (s < 7 && c < Cin) ? w[((co * 7 + r) * 7 + s) * Cin + c] : 0.f;
-  }
-}
-__global__ void unpack_stem_wgrad_kernel(const float* __restrict__ dwp, float* __restrict__ dw, int Cout, int Cin,
-                                         int Cp, int KW) {
-  const int total = Cout * 49 * Cin;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-    const int c = i % Cin, s = (i / Cin) % 7, r = (i / (Cin * 7)) % 7, co = i / (Cin * 49);
-    dw[i] = dwp[(co * 7 + r) * KW + s * Cp + c];
-  }
-}
-
-int tbn_launch_pack_stem_weight(const float* w, float* wp, int Cout, int Cin, int Cp, int KW, hipStream_t st) {
-  hipLaunchKernelGGL(pack_stem_weight_kernel, dim3(cdiv(Cout * 7 * KW, 256)), dim3(256), 0, st, w, wp, Cout, Cin, Cp,
-                     KW);
-  TBN_CHECK_LAUNCH("pack_stem_weight");
-  return TBN_OK;
-}
-int tbn_launch_unpack_stem_wgrad(const float* dwp, float* dw, int Cout, int Cin, int Cp, int KW, hipStream_t st) {
-  hipLaunchKernelGGL(unpack_stem_wgrad_kernel, dim3(cdiv(Cout * 49 * Cin, 256)), dim3(256), 0, st, dwp, dw, Cout, Cin,
-                     Cp, KW);
-  TBN_CHECK_LAUNCH("unpack_stem_wgrad");
-  return TBN_OK;
-}
-
-// ---------------------------------------------------------------- single-channel stem as a space-to-depth conv
-// A 7x7 / stride 2 / pad 3 conv on ONE input channel (the audio spectrogram) wastes 25 of the 32 k-slots of a
-// padded filter row.  It is exactly a 4x4 / stride 1 conv on the 2x2 space-to-depth image (4 channels = the pixel
-// parities (y&1, x&1), half the height / width): x[2oy-3+r] with r+1 = 2a+py reads s2d row oy-2+a, parity py, so the
-// taps are a, b in 0..3 with "pad 2" on the top / left (a = py = 0 has no source tap: zero weight).  A filter row is
-// then 4 pixels x 4 parities = 16 real of 32 slots and K = 4 x 32 instead of 7 x 32.
-__global__ __launch_bounds__(256) void nchw1_to_s2d_kernel(const float* __restrict__ in, float* __restrict__ out, int N,
-                                                           int H, int W) {
-  const int H2 = H >> 1, W2 = W >> 1;
-  const size_t total = (size_t)N * H2 * W2;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-    const int X = (int)(i % W2);
-    size_t t = i / W2;
-    const int Y = (int)(t % H2), n = (int)(t / H2);
-    const float* r0 = in + ((size_t)n * H + 2 * Y) * W + 2 * X;
-    const float2 a = *reinterpret_cast<const float2*>(r0);          // W even, 2X even: 8-byte aligned
-    const float2 b = *reinterpret_cast<const float2*>(r0 + W);
-    reinterpret_cast<float4*>(out)[i] = make_float4(a.x, a.y, b.x, b.y);   // channel = py*2 + px
-  }
-}
-
-int tbn_launch_nchw1_to_s2d(const float* in, float* out, int N, int H, int W, hipStream_t st) {
-  TBN_REQUIRE(H % 2 == 0 && W % 2 == 0, "nchw1_to_s2d: H and W must be even");
-  hipLaunchKernelGGL(nchw1_to_s2d_kernel, dim3(ew_grid((size_t)N * (H / 2) * (W / 2))), dim3(256), 0, st, in, out, N, H,
-                     W);
-  TBN_CHECK_LAUNCH("nchw1_to_s2d");
-  return TBN_OK;
-}
-
-// weights [Cout][7][7] -> [Cout][4][32]: slot (a, b*4 + py*2 + px) = w[2a+py-1][2b+px-1] (zero outside 0..6, zero tail)
-__global__ void pack_stem_weight_s2d_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout) {
-  const int total = Cout * 4 * 32;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-    const int k = i & 31, a = (i >> 5) & 3, co = i >> 7;
-    float v = 0.f;
-    if (k < 16) {
-      const int b = k >> 2, py = (k >> 1) & 1, px = k & 1;
-      const int r = 2 * a + py - 1, s2 = 2 * b + px - 1;
-      if (r >= 0 && r < 7 && s2 >= 0 && s2 < 7) v = w[(co * 7 + r) * 7 + s2];
+    for (int q = 0; q < 4; ++q) {
+      const int y = y0 + (q >> 1), x = x0 + (q & 1);
+      ok[q] = (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+      off[q] = ok[q] ? (size_t)y * W + x : 0;
     }
-    wp[i] = v;
+    float* o = out + i * (size_t)(4 * C);
+    if (CT > 0) {
+      float v[4 * (CT > 0 ? CT : 1)];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int c = 0; c < CT; ++c) v[q * CT + c] = ok[q] ? src[(size_t)c * hw + off[q]] : 0.f;
+#pragma unroll
+      for (int c = 0; c < CT; ++c)
+        reinterpret_cast<float4*>(o)[c] = make_float4(v[4 * c], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]);
+    } else {
+      for (int q = 0; q < 4; ++q)
+        for (int c = 0; c < C; ++c) o[q * C + c] = ok[q] ? src[(size_t)c * hw + off[q]] : 0.f;
+    }
   }
 }
-__global__ void unpack_stem_wgrad_s2d_kernel(const float* __restrict__ dwp, float* __restrict__ dw, int Cout) {
-  const int total = Cout * 49;
+
+int tbn_launch_nchw_to_s2d_pad(const float* in, float* out, int N, int C, int H, int W, hipStream_t st) {
+  TBN_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0, "nchw_to_s2d_pad: empty input");
+  const int HP = (H + 1) / 2 + 3, WP = (W + 1) / 2 + 3;
+  const dim3 grid(ew_grid((size_t)N * HP * WP));
+  switch (C) {
+    case 1: hipLaunchKernelGGL(nchw_to_s2d_pad_kernel<1>, grid, dim3(256), 0, st, in, out, N, C, H, W, HP, WP); break;
+    case 3: hipLaunchKernelGGL(nchw_to_s2d_pad_kernel<3>, grid, dim3(256), 0, st, in, out, N, C, H, W, HP, WP); break;
+    case 10: hipLaunchKernelGGL(nchw_to_s2d_pad_kernel<10>, grid, dim3(256), 0, st, in, out, N, C, H, W, HP, WP); break;
+    default: hipLaunchKernelGGL(nchw_to_s2d_pad_kernel<0>, grid, dim3(256), 0, st, in, out, N, C, H, W, HP, WP); break;
+  }
+  TBN_CHECK_LAUNCH("nchw_to_s2d_pad");
+  return TBN_OK;
+}
+
+// weights [Cout][7][7][C] -> [Cout][K = 64C]: k = (a*4 + b)*4C + (py*2 + px)*C + c holds w[2a+py-1][2b+px-1][c]
+// (zero where that tap lies outside 0..6)
+__global__ void pack_stem_weight_s2d_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int C) {
+  const int K = 64 * C, total = Cout * K;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-    const int s2 = i % 7, r = (i / 7) % 7, co = i / 49;
-    const int a = (r + 1) >> 1, py = (r + 1) & 1, b = (s2 + 1) >> 1, px = (s2 + 1) & 1;
-    dw[i] = dwp[(co * 4 + a) * 32 + b * 4 + py * 2 + px];
+    const int co = i / K, k = i - co * K;
+    const int ab = k / (4 * C), cq = k - ab * 4 * C, a = ab >> 2, b = ab & 3;
+    const int par = cq / C, c = cq - par * C, py = par >> 1, px = par & 1;
+    const int r = 2 * a + py - 1, s2 = 2 * b + px - 1;
+    wp[i] = (r >= 0 && r < 7 && s2 >= 0 && s2 < 7) ? w[((co * 7 + r) * 7 + s2) * C + c] : 0.f;
   }
 }
-int tbn_launch_pack_stem_weight_s2d(const float* w, float* wp, int Cout, hipStream_t st) {
-  hipLaunchKernelGGL(pack_stem_weight_s2d_kernel, dim3(cdiv(Cout * 128, 256)), dim3(256), 0, st, w, wp, Cout);
+__global__ void unpack_stem_wgrad_s2d_kernel(const float* __restrict__ dwp, float* __restrict__ dw, int Cout, int C) {
+  const int total = Cout * 49 * C;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int c = i % C, s2 = (i / C) % 7, r = (i / (7 * C)) % 7, co = i / (49 * C);
+    const int a = (r + 1) >> 1, py = (r + 1) & 1, b = (s2 + 1) >> 1, px = (s2 + 1) & 1;
+    dw[i] = dwp[(size_t)co * 64 * C + (a * 4 + b) * 4 * C + (py * 2 + px) * C + c];
+  }
+}
+int tbn_launch_pack_stem_weight_s2d(const float* w, float* wp, int Cout, int C, hipStream_t st) {
+  hipLaunchKernelGGL(pack_stem_weight_s2d_kernel, dim3(cdiv(Cout * 64 * C, 256)), dim3(256), 0, st, w, wp, Cout, C);
   TBN_CHECK_LAUNCH("pack_stem_weight_s2d");
   return TBN_OK;
 }
-int tbn_launch_unpack_stem_wgrad_s2d(const float* dwp, float* dw, int Cout, hipStream_t st) {
-  hipLaunchKernelGGL(unpack_stem_wgrad_s2d_kernel, dim3(cdiv(Cout * 49, 256)), dim3(256), 0, st, dwp, dw, Cout);
+int tbn_launch_unpack_stem_wgrad_s2d(const float* dwp, float* dw, int Cout, int C, hipStream_t st) {
+  hipLaunchKernelGGL(unpack_stem_wgrad_s2d_kernel, dim3(cdiv(Cout * 49 * C, 256)), dim3(256), 0, st, dwp, dw, Cout, C);
   TBN_CHECK_LAUNCH("unpack_stem_wgrad_s2d");
   return TBN_OK;
 }

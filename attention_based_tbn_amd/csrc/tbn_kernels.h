@@ -43,11 +43,11 @@ struct ConvP {
   // ---- caller-facing geometry (host side fills the derived fields below from these)
   int N, H, W;            // input spatial dims (for dgrad: dims of dy)
   int OH, OW;             // full output dims
-  int Cin;                // K per tap (ROWMODE: padded filter-row length in floats)
+  int Cin;                // K per tap (ROWMODE: floats of one contiguous input run; R runs make the K of a pixel)
   int Cout;
   int R, S, stride, pad, up;
   int M, K;               // GEMM M (output pixels of this launch) and reduction length of this launch
-  int cp;                 // ROWMODE: channels per pixel of the padded NHWC input
+  int cp;                 // ROWMODE: floats per pixel of the (physically zero-padded) input image
   int tiles_m, tiles_n;
   int mode, flags;
   double alg_flops;       // host only: algorithmic FLOPs of this launch (profiling)
@@ -67,6 +67,7 @@ struct ConvP {
   int tap_off[9];                       // byte offset of tap t relative to the window origin pixel
   int ty0, tny, tx0, tnx;               // the taps form a grid: tap (ry, rx) = (ty0 + ry, tx0 + rx), t = ry*tnx + rx
   FastDiv div_ohw, div_ow;              // m -> (n, a, b) without integer division
+  FastDiv div_rl4;                      // ROWMODE: float4 index inside K -> (run, float4 inside the run)
 };
 
 struct WgradP {
@@ -75,15 +76,15 @@ struct WgradP {
   float* out;
   int dy_ld, x_ld;
   int N, H, W, OH, OW;
-  int Cin, Cout;          // per tap (ROWMODE: Cin = padded row length)
+  int Cin, Cout;          // per tap (ROWMODE: taps = 1 and Cin = the whole packed K of a pixel = R runs of `rl` floats)
   int R, S, stride, pad;
   int taps;
   int M, K;
-  int cp;
+  int cp, rl;             // ROWMODE: floats per pixel of the padded input image / floats per contiguous run
   int tiles_co, tiles_ci;
   int rows_per_split;
   int mt, nt;             // host only: tile (32-column sub-tiles of Cout / Cin per workgroup), 0 = heuristic
-  FastDiv div_ohw, div_ow;
+  FastDiv div_ohw, div_ow, div_rl4;
   double alg_flops;       // host only
   unsigned dy_bytes, x_bytes;
   int ablate;             // timing ablations, honoured by -DTBN_ABLATE=1 builds only (scripts/wgrad_ablate.py)
@@ -197,9 +198,6 @@ int tbn_launch_spatial_mean_fwd(const float* in, int in_ld, float* out, int out_
                                 int freq_only, hipStream_t st);
 int tbn_launch_spatial_mean_bwd(const float* dout, int dout_ld, float* din, int din_ld, int N, int H, int W, int C,
                                 int freq_only, hipStream_t st);
-int tbn_launch_nchw_to_nhwc_pad(const float* in, float* out, int N, int C, int H, int W, int Cp, hipStream_t st);
-int tbn_launch_nchw1_to_s2d(const float* in, float* out, int N, int H, int W, hipStream_t st);
-int tbn_launch_pack_stem_weight_s2d(const float* w, float* wp, int Cout, hipStream_t st);
-int tbn_launch_unpack_stem_wgrad_s2d(const float* dwp, float* dw, int Cout, hipStream_t st);
-int tbn_launch_pack_stem_weight(const float* w, float* wp, int Cout, int Cin, int Cp, int KW, hipStream_t st);
-int tbn_launch_unpack_stem_wgrad(const float* dwp, float* dw, int Cout, int Cin, int Cp, int KW, hipStream_t st);
+int tbn_launch_nchw_to_s2d_pad(const float* in, float* out, int N, int C, int H, int W, hipStream_t st);
+int tbn_launch_pack_stem_weight_s2d(const float* w, float* wp, int Cout, int C, hipStream_t st);
+int tbn_launch_unpack_stem_wgrad_s2d(const float* dwp, float* dw, int Cout, int C, hipStream_t st);
