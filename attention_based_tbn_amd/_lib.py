@@ -129,8 +129,23 @@ def check(rc, what=""):
         raise TbnHipError(f"{what} failed (rc={rc}): {msg.decode() if msg else ''}")
 
 
+TRACE = None    # diagnostics (bench.py --trace-streams): a list collects (name, host t0, host t1, event0, event1) per
+                # backbone forward / backward call, events recorded on the stream the call launches on
+
+
 def call(name, *args):
     """Invoke a status-returning entry point and raise on error."""
+    if TRACE is not None and name in ("tbn_backbone_forward", "tbn_backbone_backward"):
+        import time
+        import torch
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        t0 = time.perf_counter()
+        check(getattr(lib(), name)(*args), name)
+        t1 = time.perf_counter()
+        e1.record()
+        TRACE.append((name, t0, t1, e0, e1))
+        return
     check(getattr(lib(), name)(*args), name)
 
 

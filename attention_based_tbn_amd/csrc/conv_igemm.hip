@@ -81,11 +81,13 @@ __device__ __forceinline__ float4 buf_load4(i32x4 r, unsigned voff, unsigned sof
 // statistics need no masking.  Stores are buffer stores: the lane offset is computed once per 32x32
 // sub-tile, the per-register row step rides in the scalar offset -> no VALU address math, no branches.
 // Precondition: every wave has passed a barrier after its last LDS tile read (`lds` is reused for the partial sums).
-template <int MT, int NT, int EPI, bool RED>
+// WM = waves stacked along M: 4 (the GEMM bodies whose waves own 32*MT rows each) or 1 (conv_sk4_body: ONE wave holds the
+// finished (32*MT) x (32*NT) tile, the partial sums go straight to global memory, no barrier).
+template <int MT, int NT, int EPI, bool RED, int WM = 4>
 __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[MT][NT], float* lds, const int tm,
                                               const int m0, const int n0) {
-  constexpr int BM = 128 * MT, BN = 32 * NT;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int BM = 32 * WM * MT, BN = 32 * NT;
+  const int tid = threadIdx.x, lane = tid & 63, wave = WM == 1 ? 0 : (tid >> 6);
   const int lrow = lane & 31, lhalf = lane >> 5;
   float* red = lds;  // [2][4 waves][BN] for the BN-statistics partials (tiles are dead now)
   const int mrow0 = m0 + wave * 32 * MT + 4 * lhalf;  // + i*32 + 8*g + q  (accumulator register e = 4*g + q)
@@ -116,7 +118,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[MT][
       }
     }
     // fused BN-backward reduce: the producer layer of these 32 columns (block-uniform, segments start on x32 columns)
-    int rs = 0;
+    int rs = 0, lc = 0;
     bool red_on = false;
     i32x4 y_rsrc = o_rsrc;
     unsigned ycol_off = 0u;
@@ -130,7 +132,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[MT][
       if (red_on) {
         y_rsrc = make_rsrc(p.red[rs].y, p.red[rs].y_bytes);
         yld = p.red[rs].y_ld;
-        const int lc = col - p.red[rs].col_begin;
+        lc = col - p.red[rs].col_begin;
         ycol_off = (unsigned)lc * 4u;
         if (lc < p.red[rs].C) {
           const float* stp = p.red[rs].stats + p.red[rs].c_off + lc;
@@ -195,13 +197,24 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[MT][
     if (SUMS) {
       s1 += __shfl_xor(s1, 32);
       s2 += __shfl_xor(s2, 32);
-      if (lhalf == 0) {
+      if (WM == 1) {   // the wave holds the whole tile: its column sums ARE the tile's partial row
+        if (lhalf == 0 && col_ok) {
+          if (EPI == 1) {
+            p.stat_partial[((size_t)tm * 2 + 0) * p.Cout + col] = s1;
+            p.stat_partial[((size_t)tm * 2 + 1) * p.Cout + col] = s2;
+          } else if (red_on && lc < p.red[rs].C) {
+            float* part = p.red[rs].partial + (size_t)(p.red_row0 + tm) * 2 * p.red[rs].C;
+            part[lc] = s1;
+            part[p.red[rs].C + lc] = s2;
+          }
+        }
+      } else if (lhalf == 0) {
         red[(0 * 4 + wave) * BN + j * 32 + lrow] = s1;
         red[(1 * 4 + wave) * BN + j * 32 + lrow] = s2;
       }
     }
   }
-  if (SUMS) {
+  if (SUMS && WM != 1) {
     __syncthreads();
     if (tid < BN && n0 + tid < p.Cout) {
       float t1 = 0.f, t2 = 0.f;
@@ -796,6 +809,173 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(ConvP p) {
   conv_dma_body<MT, NT, EPI, RED>(p, blockIdx.x, lds);
 }
 
+// ------------------------------------------------------------------------------------------
+// Small-M GEMMs (the 7x7 / 8x8 maps: M = 4704 rows at 96 frames; the head Linear layers: M = 96): with 128-row tiles
+// the grid is 37 M-tiles x a few N-tiles -- e.g. 259 workgroups for Cout = 224, one round of 256 CUs plus three
+// stragglers that double the launch time.  Here a workgroup owns a (32*MT) x (32*NT) tile and its FOUR WAVES SPLIT K
+// (wave w takes the 32-float K chunks w, w+4, ...): 4x more, 4x smaller tiles (1029 for that layer) that balance over the
+// CUs, and K = 9 * Cin is long enough that a quarter of it still amortises the tile's prologue.  Each wave stages its own
+// A / B chunk in a wave-private LDS tile -- no workgroup barrier in the K loop (wave-private LDS operations execute
+// in program order) -- the four partial tiles are summed through LDS in fixed order (deterministic) and wave 0 runs the
+// usual epilogue on the finished tile (conv_epilogue with WM = 1: partial-sum rows go straight to global memory).
+template <int MT, int NT, int EPI, bool RED>
+__device__ __forceinline__ void conv_sk4_body(const ConvP& p, const int bid, float* lds) {
+  constexpr int BM = 32 * MT, BN = 32 * NT;
+  constexpr int AR = 4 * MT, BR = 4 * NT;   // float4 loads per lane per K-step: 8 tile rows per wave instruction
+  constexpr int TILE_F = (BM + BN) * LDT;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nb = p.tiles_m * p.tiles_n;
+  const int q8 = nb >> 3, r8 = nb & 7, xcd = bid & 7, idx = bid >> 3;
+  const int nid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+  const int tm = nid / p.tiles_n, tn = nid - tm * p.tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const i32x4 in_rsrc = make_rsrc(p.in, p.in_bytes);
+  const i32x4 wt_rsrc = make_rsrc(p.wt, p.wt_bytes);
+
+  const int c4 = lane & 7, r0 = lane >> 3;
+  unsigned a_off[AR], a_mask[AR];
+#pragma unroll
+  for (int i = 0; i < AR; ++i) {
+    const int m = m0 + r0 + 8 * i;
+    unsigned mask = 0, off = 0;
+    if (m < p.M) {
+      const uint32_t n = fdiv((uint32_t)m, p.div_ohw);
+      const uint32_t rem = (uint32_t)m - n * p.div_ohw.d;
+      const uint32_t a = fdiv(rem, p.div_ow);
+      const uint32_t b = rem - a * p.div_ow.d;
+      const int iy0 = (int)a * p.in_sy, ix0 = (int)b * p.in_sx;
+      unsigned yb = 0, xb = 0;
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+        if (r < p.tny && (unsigned)(iy0 + p.ty0 + r) < (unsigned)p.H) yb |= 1u << r;
+      off = (unsigned)((((int)n * p.H + iy0) * p.W + ix0) * p.in_ld * 4);
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        if (c < p.tnx && (unsigned)(ix0 + p.tx0 + c) < (unsigned)p.W) xb |= 1u << c;
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+        if ((yb >> r) & 1u) mask |= xb << (r * p.tnx);
+    }
+    a_off[i] = off;
+    a_mask[i] = mask;
+  }
+  unsigned b_voff[BR];
+#pragma unroll
+  for (int i = 0; i < BR; ++i) b_voff[i] = (unsigned)(n0 + r0 + 8 * i) * (unsigned)p.Krow * 4u + (unsigned)c4 * 16u;
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int ksteps = p.K >> 5, cpt = p.Cin >> 5;
+  int l_tap = wave / cpt, l_c0 = (wave - l_tap * cpt) * 32;   // (tap, channel offset) of this wave's next chunk (scalar)
+  float* As = lds + wave * TILE_F;
+  float* Bs = As + BM * LDT;
+  float4 ra[AR], rb[BR];
+  auto load_tiles = [&]() {
+    const unsigned toff = (unsigned)p.tap_off[l_tap] + (unsigned)c4 * 16u, soff = (unsigned)l_c0 * 4u;
+#pragma unroll
+    for (int i = 0; i < AR; ++i) ra[i] = buf_load4(in_rsrc, ((a_mask[i] >> l_tap) & 1u) ? a_off[i] + toff : TBN_OOB, soff);
+    const unsigned koff = ((unsigned)p.tap_koff[l_tap] + (unsigned)l_c0) * 4u;
+#pragma unroll
+    for (int i = 0; i < BR; ++i) rb[i] = buf_load4(wt_rsrc, b_voff[i], koff);   // rows >= Cout: beyond wt_bytes -> zeros
+    l_c0 += 128;                 // four chunks on
+    while (l_c0 >= p.Cin) {
+      l_c0 -= p.Cin;
+      ++l_tap;
+    }
+  };
+  auto store_tiles = [&]() {
+#pragma unroll
+    for (int i = 0; i < AR; ++i) *reinterpret_cast<float4*>(&As[(r0 + 8 * i) * LDT + c4 * 4]) = ra[i];
+#pragma unroll
+    for (int i = 0; i < BR; ++i) *reinterpret_cast<float4*>(&Bs[(r0 + 8 * i) * LDT + c4 * 4]) = rb[i];
+  };
+  const int lrow = lane & 31, lhalf = lane >> 5;
+  if (wave < ksteps) {
+    load_tiles();
+    store_tiles();
+  }
+  for (int q = wave; q < ksteps; q += 4) {
+    const bool more = q + 4 < ksteps;
+    __builtin_amdgcn_wave_barrier();
+    if (more) load_tiles();   // in flight under the MFMA phase
+    float4 fa[2][MT], fb[2][NT];
+    auto frag_load = [&](int buf, int kg) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+        fa[buf][i] = *reinterpret_cast<const float4*>(&As[(i * 32 + lrow) * LDT + kg * 8 + lhalf * 4]);
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+        fb[buf][j] = *reinterpret_cast<const float4*>(&Bs[(j * 32 + lrow) * LDT + kg * 8 + lhalf * 4]);
+    };
+    auto mfma_group = [&](int buf) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[buf][i].x, fb[buf][j].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[buf][i].y, fb[buf][j].y, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[buf][i].z, fb[buf][j].z, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[buf][i].w, fb[buf][j].w, acc[i][j], 0, 0, 0);
+        }
+    };
+    frag_load(0, 0);
+    frag_load(1, 1);
+    mfma_group(0);
+    frag_load(0, 2);
+    mfma_group(1);
+    frag_load(1, 3);
+    mfma_group(0);
+    mfma_group(1);
+    {
+      constexpr int NR = MT + NT, NM = 4 * MT * NT;
+      __builtin_amdgcn_sched_group_barrier(0x100, 2 * NR, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, NR, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, NR, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 2 * NM, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (more) store_tiles();   // behind this step's fragment reads in the wave's LDS queue
+  }
+  __syncthreads();   // the reduction buffer overlays every wave's tile
+  float* red = lds;  // [3 waves][MT*NT][16][64 lanes]
+  if (wave > 0) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) red[(((wave - 1) * MT * NT + i * NT + j) * 16 + e) * 64 + lane] = acc[i][j][e];
+  }
+  __syncthreads();
+  if (wave > 0) return;
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int o = ((i * NT + j) * 16 + e) * 64 + lane;
+        acc[i][j][e] = ((acc[i][j][e] + red[o]) + red[MT * NT * 1024 + o]) + red[2 * MT * NT * 1024 + o];
+      }
+  conv_epilogue<MT, NT, EPI, RED, 1>(p, acc, lds, tm, m0, n0);
+}
+
+template <int MT, int NT, int EPI, bool RED>
+__global__ __launch_bounds__(256) void conv_sk4_kernel(ConvP p) {
+  __shared__ __attribute__((aligned(16))) float lds[4 * (32 * MT + 32 * NT) * LDT];
+  conv_sk4_body<MT, NT, EPI, RED>(p, blockIdx.x, lds);
+}
+
 // The four output-parity phases of a stride-2 data gradient in ONE launch: each phase alone is a small GEMM
 // (M / 4 rows, 1-4 taps) that leaves most CUs idle; a workgroup finds its phase by a scalar scan.
 struct ConvPhases {
@@ -1118,6 +1298,19 @@ static int launch_halo(const ConvP& p, size_t lds_bytes, hipStream_t st) {
 }
 
 template <int MT, int NT>
+static void launch_sk4(const ConvP& p, hipStream_t st) {
+  const dim3 grid(p.tiles_m * p.tiles_n);
+  if (p.mode == CONV_EPI_STATS)
+    hipLaunchKernelGGL((conv_sk4_kernel<MT, NT, 1, false>), grid, dim3(256), 0, st, p);
+  else if (p.mode == CONV_EPI_EVAL)
+    hipLaunchKernelGGL((conv_sk4_kernel<MT, NT, 2, false>), grid, dim3(256), 0, st, p);
+  else if (p.nred > 0)
+    hipLaunchKernelGGL((conv_sk4_kernel<MT, NT, 0, true>), grid, dim3(256), 0, st, p);
+  else
+    hipLaunchKernelGGL((conv_sk4_kernel<MT, NT, 0, false>), grid, dim3(256), 0, st, p);
+}
+
+template <int MT, int NT>
 static void launch_dma(const ConvP& p, hipStream_t st) {
   const dim3 grid(p.tiles_m * p.tiles_n);
   if (p.mode == CONV_EPI_STATS)
@@ -1155,13 +1348,13 @@ void tbn_conv_pick_tile(int M, int Cout, int K, int* mt_out, int* nt_out) {
 }
 
 // number of partial rows (M tiles) a data-gradient launch with a fused BN-backward reduce writes per reduce segment
-int tbn_conv_red_rows(int N, int OH, int OW, int up, int mt) {
-  if (up == 1) return cdiv(N * OH * OW, 128 * mt);
+int tbn_conv_red_rows(int N, int OH, int OW, int up, int tile_rows) {
+  if (up == 1) return cdiv(N * OH * OW, tile_rows);
   int rows = 0;
   for (int py = 0; py < 2; ++py)
     for (int px = 0; px < 2; ++px) {
       const int ohs = (OH - py + 1) / 2, ows = (OW - px + 1) / 2;
-      if (ohs > 0 && ows > 0) rows += cdiv(N * ohs * ows, 128 * mt);
+      if (ohs > 0 && ows > 0) rows += cdiv(N * ohs * ows, tile_rows);
     }
   return rows;
 }
@@ -1177,10 +1370,34 @@ static double conv_alg_bytes(const ConvP& p, int rowmode) {
 }
 
 static int launch_conv_tiles(ConvP& p, int rowmode, int mt, int nt, hipStream_t st) {
+  if ((mt <= 0 || nt <= 0) && !rowmode && p.out_sy == 1 && p.out_sx == 1) {
+    // heuristic launches (the head Linear layers: M = 96 ... 768 rows): a grid of 128-row tiles that leaves most CUs
+    // idle takes the split-K tile kernel instead (never with partial-sum epilogues: their row count is the caller's)
+    if (p.halo == 0 && p.mode != CONV_EPI_STATS && p.nred == 0 && p.K >= 256 &&
+        cdiv(p.M, 128) * cdiv(p.Cout, 32) <= 128)
+      p.halo = 3;
+    if (p.halo == 3) mt = nt = 1;
+  }
   if (mt <= 0 || nt <= 0) tbn_conv_pick_tile(p.M, p.Cout, p.K, &mt, &nt);
   if (p.stages != 1 && p.stages != 2) p.stages = (mt == 1) ? 2 : 1;  // big tiles: keep 2 workgroups per CU
   p.tiles_m = cdiv(p.M, 128 * mt);
   p.tiles_n = cdiv(p.Cout, 32 * nt);
+  if (p.halo == 3 && !rowmode) {   // small-M layers: 32-row tiles, the four waves split K
+    const bool scatter = (p.out_sy != 1) || (p.out_sx != 1);
+    TBN_REQUIRE(!scatter && mt <= 2 && nt <= 2, "conv: the split-K tile kernel does not handle this launch");
+    p.tiles_m = cdiv(p.M, 32 * mt);
+    char nm[64];
+    const int epi = p.mode == CONV_EPI_STATS ? 1 : (p.mode == CONV_EPI_EVAL ? 2 : 0);
+    snprintf(nm, sizeof(nm), "conv_sk4_kernel<%d, %d, %d%s>", mt, nt, epi, (p.nred > 0 && epi == 0) ? ", true" : "");
+    tbn_prof_begin(nm, p.alg_flops, st, conv_alg_bytes(p, rowmode));
+#define TBN_SCASE(MTv, NTv) \
+  if (mt == MTv && nt == NTv) launch_sk4<MTv, NTv>(p, st);
+    TBN_SCASE(1, 1) TBN_SCASE(1, 2) TBN_SCASE(2, 1) TBN_SCASE(2, 2)
+#undef TBN_SCASE
+    tbn_prof_end(st);
+    TBN_CHECK_LAUNCH("conv_sk4");
+    return TBN_OK;
+  }
   if (p.halo == 2 && !rowmode) {   // LDS-DMA staging
     const bool scatter = (p.out_sy != 1) || (p.out_sx != 1);
     TBN_REQUIRE(!scatter && mt <= 2 && nt <= 4, "conv: the LDS-DMA kernel does not handle this launch");
@@ -1275,6 +1492,7 @@ static int conv_prepare(ConvP& p, int rowmode, int* single) {
   TBN_REQUIRE(p.up == 1 || p.up == 2, "conv: up must be 1 or 2");
   if (p.flags & CONV_FLAG_HALO) p.halo = 1;
   if (p.flags & CONV_FLAG_DMA) p.halo = 2;
+  if (p.flags & CONV_FLAG_SK4) p.halo = 3;
   TBN_REQUIRE(p.M > 0, "conv: empty problem");
   const size_t in_bytes = (size_t)p.N * p.H * p.W * (rowmode ? p.cp : p.in_ld) * sizeof(float);
   TBN_REQUIRE(in_bytes < (1ull << 31), "conv: input extent %zu B >= 2 GiB (process the frames in chunks)", in_bytes);

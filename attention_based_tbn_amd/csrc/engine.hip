@@ -236,6 +236,11 @@ void add_bn_conv(tbn_backbone_plan* P, int ci) {
   add_bn(P, n, cs, ps);
 }
 
+// rows of the GEMM's M dimension per workgroup tile = rows per statistics / reduce partial row: the split-K tile kernel
+// (variant 3, layers of at most kSk4MaxRows rows) has 32-row wave tiles, every other kernel 128
+constexpr int kSk4MaxRows = 32768;
+inline int tile_rows(int variant, int mt) { return (variant == 3 ? 32 : 128) * mt; }
+
 // false: the input size makes the reference graph itself inconsistent (its torch.cat of a stride-2 conv branch and the
 // ceil-mode pass-through max pool raises)
 bool build_graph(tbn_backbone_plan* P) {
@@ -488,7 +493,7 @@ void plan_memory(tbn_backbone_plan* P) {
     const int M = (int)(R * c.outH * c.outW);
     const int K = c.stem ? P->stem_rows * P->kw : c.k * c.k * c.cin;
     tbn_conv_pick_tile(M, c.cout, K, &c.mt, &c.nt);
-    size_t a = (size_t)cdiv(M, 128) * 2 * c.cout;  // worst case (mt = 1): autotune may pick any tile
+    size_t a = (size_t)cdiv(M, M <= kSk4MaxRows ? 32 : 128) * 2 * c.cout;  // worst case (mt = 1): autotune may pick any tile
     if (a > partial) partial = a;
     for (int k = 0; k < c.nparts; ++k) {
       size_t bparts = (size_t)tbn_bn_bwd_parts(M, c.parts[k].cout) * 2 * c.parts[k].cout;
@@ -537,7 +542,8 @@ void plan_memory(tbn_backbone_plan* P) {
     for (int k = 0; k < c.nparts; ++k)
       if (c.parts[k].red_src >= 0) {
         const Buf& db = P->bufs[c.parts[k].dst_buf];
-        c.parts[k].bpart_off = take(((size_t)cdiv((int)(R * db.H * db.W), 128) + 4) * 2 * c.parts[k].cout);
+        const int drows = (int)(R * db.H * db.W);
+        c.parts[k].bpart_off = take(((size_t)cdiv(drows, drows <= kSk4MaxRows ? 32 : 128) + 4) * 2 * c.parts[k].cout);
       }
   P->coef_off = take(TBN_BN_MAXL * 3 * 1024);
   P->wsplit_off = take(wsplit);
@@ -960,7 +966,7 @@ int tbn_backbone_forward(const tbn_backbone_plan* P, int training, const float* 
         const Pool& pl = P->pools[c0.fuse_pool];
         const Buf& ob = P->bufs[pl.outbuf];
         if (!diag_skip(2)) {
-          TBN_TRY(tbn_launch_bn_finalize(ws + P->partial_off + (size_t)c0.slot * P->partial_floats, cdiv(M, 128 * c0.mt), M,
+          TBN_TRY(tbn_launch_bn_finalize(ws + P->partial_off + (size_t)c0.slot * P->partial_floats, cdiv(M, tile_rows(c0.halo, c0.mt)), M,
                                          q.cout, prm->gamma + q.c_off, prm->beta + q.c_off, prm->bias + q.c_off,
                                          prm->running_mean + q.c_off, prm->running_var + q.c_off, prm->momentum, prm->eps,
                                          mean + q.c_off, rstd + q.c_off, scale + q.c_off, shift + q.c_off, st));
@@ -997,7 +1003,10 @@ int tbn_backbone_forward(const tbn_backbone_plan* P, int training, const float* 
           int fmt = c.mt;      // M tile of the launch that wrote the statistics partials (a paired launch has its own)
           if (c.pair_next >= 0 && c.pair_fwd) fmt = c.pf_mt;
           if (c.pair_prev >= 0 && P->convs[c.pair_prev].pair_fwd) fmt = P->convs[c.pair_prev].pf_mt;
-          L.nparts = cdiv(M, 128 * fmt);
+          int frows = tile_rows(c.halo, c.mt);
+          if (fmt != c.mt || (c.pair_next >= 0 && c.pair_fwd) || (c.pair_prev >= 0 && P->convs[c.pair_prev].pair_fwd))
+            frows = 128 * fmt;
+          L.nparts = cdiv(M, frows);
         }
         L.gamma = prm->gamma + q.c_off;
         L.beta = prm->beta + q.c_off;
@@ -1102,11 +1111,15 @@ int tbn_backbone_autotune(tbn_backbone_plan* P, int training, const tbn_backbone
       int ncand = 0;
       for (int mt = 1; mt <= 2 && rc == TBN_OK; ++mt)
         for (int nt = 1; nt <= 4 && rc == TBN_OK; ++nt)
-          for (int stg = 0; stg <= 3 && rc == TBN_OK; ++stg) {   // 0: LDS-halo kernel (3x3 / stride-1 layers), 3: LDS-DMA
-            if (32 * (nt - 1) >= p.Cout) continue;
+          for (int stg = 0; stg <= 4 && rc == TBN_OK; ++stg) {   // 0: LDS-halo kernel (3x3 / stride-1 layers), 3: LDS-DMA,
+            if (32 * (nt - 1) >= p.Cout) continue;               // 4: 32-row tiles, waves split K (small maps)
             static const int use_dma = getenv("TBN_USE_DMA") ? atoi(getenv("TBN_USE_DMA")) : 1;
-            p.halo = stg == 0 ? 1 : (stg == 3 ? 2 : 0);
-            if (stg == 3) {
+            static const int use_sk4 = getenv("TBN_USE_SK4") ? atoi(getenv("TBN_USE_SK4")) : 1;
+            p.halo = stg == 0 ? 1 : (stg == 3 ? 2 : (stg == 4 ? 3 : 0));
+            if (stg == 4) {
+              if ((c.stem && pass == 0) || p.up != 1 || !use_sk4 || force_halo == 1 || p.M > kSk4MaxRows || mt > 2 || nt > 2)
+                continue;
+            } else if (stg == 3) {
               if ((c.stem && pass == 0) || p.up != 1 || !use_dma || force_halo == 1) continue;
             } else if (p.halo) {
               const size_t lb = (c.stem && pass == 0) ? 0 : tbn_conv_halo_lds_bytes(p, mt, nt);
@@ -1114,7 +1127,7 @@ int tbn_backbone_autotune(tbn_backbone_plan* P, int training, const tbn_backbone
             } else if (force_halo == 1 && !(c.stem && pass == 0) && tbn_conv_halo_lds_bytes(p, 1, 1) > 0) {
               continue;
             }
-            p.stages = stg == 3 ? 2 : stg;
+            p.stages = stg == 3 ? 2 : (stg == 4 ? 1 : stg);
             if (ncand >= kMaxCand) continue;
             rc = tbn_launch_conv(p, c.stem && pass == 0, mt, nt, st);     // untimed first run of the candidate
             (void)hipEventRecord(ce[2 * ncand], st);
@@ -1349,7 +1362,8 @@ int tbn_backbone_backward(const tbn_backbone_plan* P, const float* dfeatures, co
           int dmt = f.d_mt;    // M tile of the launch that wrote the partials (a paired launch has its own tile)
           if (f.pair_next >= 0 && f.pair_dgrad) dmt = f.pd_mt;
           if (f.pair_prev >= 0 && P->convs[f.pair_prev].pair_dgrad) dmt = P->convs[f.pair_prev].pd_mt;
-          L.ext_parts = tbn_conv_red_rows(R, f.inH, f.inW, f.stride, dmt);
+          const bool paired = (f.pair_next >= 0 && f.pair_dgrad) || (f.pair_prev >= 0 && P->convs[f.pair_prev].pair_dgrad);
+          L.ext_parts = tbn_conv_red_rows(R, f.inH, f.inW, f.stride, paired ? 128 * dmt : tile_rows(f.d_halo, dmt));
         } else {
           L.partial = partial + (size_t)k * P->partial_floats;
           L.ext_parts = 0;

@@ -7,7 +7,8 @@ enum {
   CONV_FLAG_ACCUM = 1,
   CONV_FLAG_RELU = 2,
   CONV_FLAG_HALO = 4,   // host only: use the LDS-halo kernel
-  CONV_FLAG_DMA = 8     // host only: use the LDS-DMA staging kernel
+  CONV_FLAG_DMA = 8,    // host only: use the LDS-DMA staging kernel
+  CONV_FLAG_SK4 = 16    // host only: 32-row tiles whose four waves split K (small-M launches)
 };
 
 // BN-backward reduce fused into a data-gradient epilogue (the launch that writes the FINAL value of dz): for the output
@@ -53,7 +54,8 @@ struct ConvP {
   double alg_flops;       // host only: algorithmic FLOPs of this launch (profiling)
   int stages;             // host only: LDS stages (1 = two barriers per K-step, 2 = double buffered); 0 = default
   int halo;               // host only: 1 = LDS-halo kernel (3x3 / stride 1 / pad 1 layers: input patch staged once per chunk),
-                          //            2 = LDS-DMA staging of the generic kernel
+                          //            2 = LDS-DMA staging of the generic kernel, 3 = 32-row tiles with the waves splitting K
+                          //            (statistics / reduce partial rows are then per 32*mt rows, not 128*mt)
   // ---- derived by tbn_launch_conv
   unsigned in_bytes, wt_bytes;          // buffer extents: out-of-range lanes read zeros (hardware check)
   unsigned seg_bytes[TBN_CONV_MAXSEG];  // extent of each output segment from seg[i].ptr
@@ -100,7 +102,7 @@ void tbn_conv_pick_tile(int M, int Cout, int K, int* mt, int* nt);
 int tbn_launch_conv(ConvP p, int rowmode, int mt, int nt, hipStream_t st);
 // two independent unit-stride convs in one launch (variant 0 LDS-halo, 1 / 2 generic with 1 / 2 LDS stages; tiles <= (2,2))
 int tbn_launch_conv_pair(ConvP a, ConvP b, int variant, int mt, int nt, hipStream_t st);
-int tbn_conv_red_rows(int N, int OH, int OW, int up, int mt);
+int tbn_conv_red_rows(int N, int OH, int OW, int up, int tile_rows);   // tile_rows = M rows per workgroup tile (128 * mt; 32 * mt for the split-K tile kernel)
 size_t tbn_conv_halo_lds_bytes(const ConvP& p, int mt, int nt);   // 0: shape not handled by the LDS-halo kernel
 void tbn_wgrad_plan(int M, int Cout, int Cin, int taps, int* mt, int* nt, int* splits, int* rows_per_split);
 size_t tbn_wgrad_workspace_floats(int M, int Cout, int Cin, int taps);

@@ -141,6 +141,9 @@ def main():
     ap.add_argument("--forward-only", action="store_true", help="time the forward pass only (training-mode BN)")
     ap.add_argument("--no-multi-stream", action="store_true", help="diagnostic: run the modality backbones on one stream")
     ap.add_argument("--no-aux-stream", action="store_true", help="diagnostic: weight gradients on the backbone's own stream")
+    ap.add_argument("--aux-streams", default=None,
+                    help="diagnostic: comma-separated modalities whose weight gradients run on a second stream "
+                         "(default: the model's policy -- only a lone backbone)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--host-inputs", action="store_true",
                     help="diagnostic (never the headline): the batch starts in pinned HOST memory every step and is copied "
@@ -151,6 +154,10 @@ def main():
     ap.add_argument("--profile-every", type=int, default=1 << 30,
                     help="bracket conv-GEMM launches with HIP events on every k-th timed step (default: the first "
                          "timed step only; 0 = never).  Profiled steps run single-stream, see DESIGN.md")
+    ap.add_argument("--trace-streams", action="store_true",
+                    help="diagnostic: after the timed loop run 3 more steps with HIP events around every backbone "
+                         "forward / backward call and print (stderr) when each ran on the GPU and how long the host took "
+                         "to issue it -- the stagger between the modality streams")
     args = ap.parse_args()
     # stdout carries exactly ONE line (the JSON result, rank 0): everything the model code prints while it builds
     # (the reference's "Freezing the batchnorms ..." notices, on every rank) goes to stderr
@@ -267,6 +274,8 @@ def main():
     multi = not args.no_multi_stream
     core.multi_stream = multi
     aux = [b_.use_aux_stream and not args.no_aux_stream for b_ in bases]   # the model's own policy unless switched off
+    if args.aux_streams is not None:
+        aux = [m in args.aux_streams.split(",") for m in modality]
     for b_, a_ in zip(bases, aux):
         b_.use_aux_stream = a_
 
@@ -308,6 +317,25 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     assert os.environ.get("TBN_DIAG_SKIP") or torch.isfinite(loss).item(), "loss is not finite"
+    if args.trace_streams and rank == 0:
+        from attention_based_tbn_amd import _lib
+        for _ in range(3):
+            torch.cuda.synchronize()
+            _lib.TRACE = []
+            ref = torch.cuda.Event(enable_timing=True)
+            ref.record()
+            h0 = time.perf_counter()
+            step()
+            h1 = time.perf_counter()
+            end = torch.cuda.Event(enable_timing=True)
+            end.record()
+            torch.cuda.synchronize()
+            tr, _lib.TRACE = _lib.TRACE, None
+            print("step: GPU %.2f ms, host issue %.2f ms" % (ref.elapsed_time(end), (h1 - h0) * 1e3), file=sys.stderr)
+            for name, t0, t1, e0, e1 in tr:
+                print("  %-22s host %6.2f -> %6.2f ms (%.2f)   GPU %6.2f -> %6.2f ms (%.2f)" %
+                      (name[4:], (t0 - h0) * 1e3, (t1 - h0) * 1e3, (t1 - t0) * 1e3, ref.elapsed_time(e0),
+                       ref.elapsed_time(e1), e0.elapsed_time(e1)), file=sys.stderr)
     exposed_ms = None
     if world > 1 and hasattr(model, "exposed_sync_ms"):
         e = model.exposed_sync_ms()

@@ -192,6 +192,43 @@ def test_conv_lds_dma_kernel_all_tiles(case):
             assert relerr(part[:, 1].double().sum(0).cpu(), (y_ref * y_ref).sum((0, 2, 3))) < TOL
 
 
+@pytest.mark.parametrize("case", CONV_CASES[:4] + [(5, 7, 7, 192, 352, 1, 1, 0), (3, 7, 7, 192, 320, 3, 1, 1), (2, 9, 11, 32, 160, 3, 1, 1),
+                                                   (3, 4, 16, 192, 256, 3, 2, 1), (1, 3, 32, 64, 96, 1, 1, 0)])
+def test_conv_split_k_tile_kernel_all_tiles(case):
+    """the small-M kernel (32-row tiles whose four waves split K, partial tiles summed through LDS in fixed order)
+    against fp64 conv2d: every (MT, NT) tile, plain / BN-statistics (one partial row per 32*MT output rows) / eval
+    epilogues, K of 1, 2, 3 and many chunks per wave, ragged M / N tiles, stride 2; bit-reproducible run to run"""
+    n, h, w, cin, cout, k, s, p = case
+    x = torch.randn(n, cin, h, w, generator=g(31))
+    wt = torch.randn(cout, cin, k, k, generator=g(32)) / (cin * k * k) ** 0.5
+    b = torch.randn(cout, generator=g(33))
+    y_ref = F.conv2d(x.double(), wt.double(), None, stride=s, padding=p)
+    oh, ow = y_ref.shape[2:]
+    xd, wd, bd = nhwc(x).to(DEV), wt.permute(0, 2, 3, 1).contiguous().to(DEV), b.to(DEV)
+    SK4 = 16
+    for mt in (1, 2):
+        for nt in (1, 2):
+            if 32 * (nt - 1) >= cout:
+                continue
+            y = torch.full((n, oh, ow, cout + 32), 3.0, device=DEV)
+            call("tbn_conv2d_fwd_tile", ptr(xd), cin, ptr(wd), ptr(bd), y.data_ptr() + 16 * 4, cout + 32, n, h, w, cin,
+                 cout, k, s, p, 0, SK4, 0, mt, nt, st())
+            assert relerr(nchw(y[..., 16:16 + cout]), y_ref + b.double().view(1, -1, 1, 1)) < TOL, (mt, nt)
+            assert float((y[..., :16] - 3).abs().max()) == 0 and float((y[..., 16 + cout:] - 3).abs().max()) == 0
+            y2 = torch.full_like(y, 3.0)
+            call("tbn_conv2d_fwd_tile", ptr(xd), cin, ptr(wd), ptr(bd), y2.data_ptr() + 16 * 4, cout + 32, n, h, w, cin,
+                 cout, k, s, p, 0, SK4, 0, mt, nt, st())
+            assert torch.equal(y, y2), (mt, nt)
+            tiles = (n * oh * ow + 32 * mt - 1) // (32 * mt)
+            part = torch.zeros(tiles, 2, cout, device=DEV)
+            yb = torch.empty(n, oh, ow, cout, device=DEV)
+            call("tbn_conv2d_fwd_tile", ptr(xd), cin, ptr(wd), ptr(bd), ptr(yb), cout, n, h, w, cin, cout, k, s, p, 1,
+                 SK4, ptr(part), mt, nt, st())
+            assert relerr(nchw(yb), y_ref) < TOL, (mt, nt)
+            assert relerr(part[:, 0].double().sum(0).cpu(), y_ref.sum((0, 2, 3))) < TOL
+            assert relerr(part[:, 1].double().sum(0).cpu(), (y_ref * y_ref).sum((0, 2, 3))) < TOL
+
+
 def test_conv3x3_halo_rejects_other_shapes():
     from attention_based_tbn_amd._lib import lib as _lib
     x = torch.zeros(1, 8, 8, 32, device=DEV)
