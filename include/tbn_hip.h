@@ -117,7 +117,12 @@ int tbn_backbone_backward(const tbn_backbone_plan* plan, const float* dfeatures,
  * training-mode BN (stat_partial[tbn_conv2d_stat_tiles()][2][cout]) -- a per-channel constant cancels in
  * batch-stat BN, so `bias` is ignored here and only enters the running mean (tbn_backbone_* does that);
  * 2 = relu(conv * scale + shift) for eval BN (`bias` ignored: fold it into shift = beta + (bias-mean)*scale).
- * replaces: each nn.Conv2d of bn_inception_audio.py:24-401 (cuDNN).  cin must be a multiple of 32. */
+ * replaces: each nn.Conv2d of bn_inception_audio.py:24-401 (cuDNN).  cin must be a multiple of 32, ksize <= 3 (the
+ * 7x7 stem exists only inside tbn_backbone_*: it reads a space-to-depth image the engine lays out itself).
+ * flags also selects the kernel variant (test / tuning aid; 0 = generic): 4 = LDS-halo (3x3 / stride 1 / pad 1 only),
+ * 8 = LDS-DMA staging, 16 = 32-row tiles whose four waves split K (statistics partial rows are then per 32*mt output
+ * rows, tiles mt, nt in {1,2}).  Without a variant flag, epilogue-0 / -2 launches of at most 128 tiles and k*k*cin >= 256
+ * (the head Linear layers, M = 96 rows) take the split-K tile kernel by themselves; every variant is deterministic. */
 int tbn_conv2d_fwd(const float* in, int in_ld, const float* weight, const float* bias, float* out, int out_ld,
                    int n, int h, int w, int cin, int cout, int ksize, int stride, int pad, int epilogue, int flags,
                    const float* scale, const float* shift, float* stat_partial, void* stream);
