@@ -33,7 +33,7 @@ t_next = rows[b][0] if b < len(rows) else t1
 def family(name):
     n = name.replace("void ", "")
     for key, fam in (("conv_wgrad", "gemm"), ("conv_igemm", "gemm"), ("conv_halo", "gemm"), ("conv_dma", "gemm"),
-                     ("conv_pair", "gemm"), ("splitk_reduce", "splitk_reduce"), ("weight_flip", "weight_flip"),
+                     ("conv_pair", "gemm"), ("conv_sk4", "gemm"), ("splitk_reduce", "splitk_reduce"), ("weight_flip", "weight_flip"),
                      ("bn_bwd", "bn_backward"), ("bn_", "bn_forward"), ("maxpool", "pool"), ("avgpool", "pool"),
                      ("pool", "pool"), ("opt_sgd", "optimizer"), ("clip", "optimizer"), ("sqnorm", "optimizer"),
                      ("nchw_to_s2d", "layout"), ("pack_stem", "layout"), ("unpack_stem", "layout"),
