@@ -1771,7 +1771,12 @@ static int pick_wtile(int c) { return (c % 96 == 0 && c % 64 != 0) ? 3 : ((c % 6
 // (fitted to a sweep of 12 layer shapes x 24 plans, scripts/wgrad_ablate.py SWEEP=1: within 2 % of the best measured
 // plan per layer, 11 % below the former "about 768 workgroups" rule on one stream).  Every split keeps >= 256 rows.
 void tbn_wgrad_plan(int M, int Cout, int Cin, int taps, int* mt, int* nt, int* splits, int* rows_per_split) {
-  if (*mt < 1 || *mt > 3) *mt = pick_wtile(Cout);
+  if ((*mt < 1 || *mt > 3) && *mt != 5) {
+    *mt = pick_wtile(Cout);
+    // 160 output channels (3c / 4c 3x3 branches): 64-wide tiles multiply 17 % zero rows; one 160-wide tile (5 sub-tiles,
+    // not the data-parallel stem path) fits exactly
+    if (Cout == 160) *mt = 5;
+  }
   if (*nt < 1 || *nt > 3) {
     *nt = pick_wtile(Cin);
     // 160 / 224 input channels: 64-wide tiles would multiply 20 / 14 % zero columns; 32-wide ones measured 5-22 %
@@ -1779,6 +1784,7 @@ void tbn_wgrad_plan(int M, int Cout, int Cin, int taps, int* mt, int* nt, int* s
     // than the padding costs).
     if (*nt == 2 && Cin % 64 != 0 && cdiv(Cin, 64) * 64 * 100 >= Cin * 112) *nt = 1;
   }
+  if (*mt == 5 && *nt == 3) *nt = 2;   // 5 x 3 sub-tiles do not fit the register file
   const int tiles = cdiv(Cout, 32 * *mt) * cdiv(Cin, 32 * *nt) * taps;
   const int max_splits = cdiv(M, 256);
   auto settle = [&](int s, int* rps) {
@@ -1793,7 +1799,7 @@ void tbn_wgrad_plan(int M, int Cout, int Cin, int taps, int* mt, int* nt, int* s
     return;
   }
 #endif
-  const int occ = (*mt == 3 || *nt == 3) ? 1 : 2;           // 248+144 / 184+96 registers vs 128+64
+  const int occ = (*mt == 3 || *nt == 3 || (*mt == 5 && *nt > 1)) ? 1 : 2;   // 248+144 / 184+96 registers vs 128+64
   const int slots = 256 * occ;
   const double step_us = *mt * *nt * 8 * 64 / 2.4e3 * occ;  // 8 k-pairs x MT*NT MFMAs of 64 cycles, SIMD shared by occ waves
   const double slab_mb = (double)Cout * Cin * taps * 4e-6;
@@ -1813,9 +1819,9 @@ void tbn_wgrad_plan(int M, int Cout, int Cin, int taps, int* mt, int* nt, int* s
 // split-K slab floats: the worst case over every tile the autotuner may choose
 size_t tbn_wgrad_workspace_floats(int M, int Cout, int Cin, int taps) {
   size_t worst = 0;
-  for (int mt = 1; mt <= 3; ++mt)
+  for (int mt = 1; mt <= 4; ++mt)
     for (int nt = 1; nt <= 3; ++nt) {
-      int m = mt, n = nt, s, rps;
+      int m = mt == 4 ? 5 : mt, n = nt, s, rps;
       tbn_wgrad_plan(M, Cout, Cin, taps, &m, &n, &s, &rps);
       const size_t need = s > 1 ? (size_t)s * Cout * taps * Cin : 0;
       if (need > worst) worst = need;
@@ -1873,7 +1879,7 @@ int tbn_launch_wgrad(WgradP p, int rowmode, float* dw, float* workspace, hipStre
       launch_wgrad<MTv, NTv, false>(p, blocks, st);                 \
   } else
   TBN_CASE(1, 1) TBN_CASE(1, 2) TBN_CASE(1, 3) TBN_CASE(2, 1) TBN_CASE(2, 2) TBN_CASE(2, 3) TBN_CASE(3, 1) TBN_CASE(3, 2)
-  TBN_CASE(3, 3) {
+  TBN_CASE(3, 3) TBN_CASE(5, 1) TBN_CASE(5, 2) {
     tbn_set_error("wgrad: unsupported tile");
     return TBN_ERR_UNSUPPORTED;
   }
