@@ -1783,6 +1783,9 @@ void tbn_wgrad_plan(int M, int Cout, int Cin, int taps, int* mt, int* nt, int* s
     // faster there (profiles/r01_wgrad_tiles.txt).  The Cout side keeps its 64-wide tiles (narrow ones lose more
     // than the padding costs).
     if (*nt == 2 && Cin % 64 != 0 && cdiv(Cin, 64) * 64 * 100 >= Cin * 112) *nt = 1;
+    // few rows, many input channels (the 1056-channel 1x1 group of 5a on the 7x7 maps): the 96-wide tile's single
+    // workgroup per CU leaves 2.8 rounds of short loops; 64-wide tiles (3 % zero columns) run two per CU
+    if (*nt == 3 && M <= 5120 && Cin >= 512) *nt = 2;   // (at 6144 rows, the 8x8 audio maps, the 96-wide tile still wins)
   }
   if (*mt == 5 && *nt == 3) *nt = 2;   // 5 x 3 sub-tiles do not fit the register file
   const int tiles = cdiv(Cout, 32 * *mt) * cdiv(Cin, 32 * *nt) * taps;
