@@ -27,6 +27,20 @@ class BackboneGrads(C.Structure):
                 ("aux_stream", c_fp)]
 
 
+class ConvRed(C.Structure):
+    _fields_ = [("y", c_fp), ("y_ld", c_i), ("col_begin", c_i), ("channels", c_i), ("stat_offset", c_i),
+                ("partial", c_fp)]
+
+
+class ConvDesc(C.Structure):
+    """include/tbn_hip.h tbn_conv_desc"""
+    _fields_ = [("inp", c_fp), ("in_ld", c_i), ("weight", c_fp), ("bias", c_fp), ("out", c_fp), ("out_ld", c_i),
+                ("n", c_i), ("h", c_i), ("w", c_i), ("cin", c_i), ("cout", c_i), ("ksize", c_i), ("stride", c_i),
+                ("pad", c_i), ("dgrad", c_i), ("epilogue", c_i), ("flags", c_i), ("stages", c_i), ("scale", c_fp),
+                ("shift", c_fp), ("stat_partial", c_fp), ("nred", c_i), ("red", ConvRed * 4), ("red_stats", c_fp),
+                ("red_stats_stride", c_i)]
+
+
 class OptTensor(C.Structure):
     _fields_ = [("param", c_fp), ("grad", c_fp), ("momentum", c_fp), ("count", c_sz)]
 
@@ -51,6 +65,7 @@ SIGNATURES = {
     "tbn_backbone_out_shape": (c_i, [C.c_void_p, C.POINTER(c_i), C.POINTER(c_i), C.POINTER(c_i)]),
     "tbn_backbone_tensor_info": (c_i, [C.c_void_p, C.c_char_p, c_i, C.POINTER(C.c_long), C.POINTER(c_i),
                                        C.POINTER(c_i), C.POINTER(c_i)]),
+    "tbn_backbone_launch_info": (c_i, [C.c_void_p, C.c_char_p, c_i, C.POINTER(c_i)]),
     "tbn_backbone_forward": (c_i, [C.c_void_p, c_i, c_fp, C.POINTER(BackboneParams), c_fp, c_sz,
                                    C.POINTER(C.c_void_p), c_fp]),
     "tbn_backbone_autotune": (c_i, [C.c_void_p, c_i, C.POINTER(BackboneParams), c_fp, c_sz, c_fp]),
@@ -60,6 +75,9 @@ SIGNATURES = {
     "tbn_conv2d_stat_tiles": (c_i, [c_i] * 8),
     "tbn_conv2d_fwd_tile": (c_i, [c_fp, c_i, c_fp, c_fp, c_fp, c_i] + [c_i] * 10 + [c_fp, c_i, c_i, c_fp]),
     "tbn_conv2d_dgrad": (c_i, [c_fp, c_i, c_fp, c_fp, c_i] + [c_i] * 9 + [c_fp, c_fp]),
+    "tbn_conv_partial_rows": (c_i, [C.POINTER(ConvDesc), c_i, c_i]),
+    "tbn_conv_launch": (c_i, [C.POINTER(ConvDesc), c_i, c_i, c_fp, c_fp]),
+    "tbn_conv_launch_pair": (c_i, [C.POINTER(ConvDesc), C.POINTER(ConvDesc), c_i, c_i, c_i, c_fp, c_fp, c_fp]),
     "tbn_conv2d_wgrad_workspace_floats": (c_sz, [c_i] * 8),
     "tbn_conv2d_wgrad": (c_i, [c_fp, c_i, c_fp, c_i, c_fp] + [c_i] * 8 + [c_fp, c_fp]),
     "tbn_linear_fwd": (c_i, [c_fp, c_i, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp]),
@@ -70,6 +88,10 @@ SIGNATURES = {
     "tbn_bn_relu_train_fwd": (c_i, [c_fp, c_i, c_i, c_fp, c_fp, c_fp, c_fp, c_f, c_f, c_fp, c_fp, c_fp, c_fp, c_fp,
                                     c_i, c_fp, c_fp]),
     "tbn_bn_relu_train_bwd": (c_i, [c_fp, c_i, c_fp, c_i, c_i, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp]),
+    "tbn_bn_relu_maxpool_train_fwd": (c_i, [c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp, c_f, c_f, c_fp, c_fp, c_fp,
+                                            c_fp, c_fp, c_i, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp]),
+    "tbn_bn_relu_maxpool_train_bwd": (c_i, [c_fp, c_i, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_fp, c_fp,
+                                            c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp]),
     "tbn_maxpool3_fwd": (c_i, [c_fp, c_i, c_fp, c_i, c_fp] + [c_i] * 8 + [c_fp]),
     "tbn_maxpool3_bwd": (c_i, [c_fp, c_i, c_fp, c_fp, c_i] + [c_i] * 9 + [c_fp]),
     "tbn_avgpool3_fwd": (c_i, [c_fp, c_i, c_fp, c_i] + [c_i] * 5 + [c_fp]),

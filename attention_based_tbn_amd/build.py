@@ -8,7 +8,13 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libtbn_hip.so")
 SOURCES = ["api.hip", "conv_igemm.hip", "bn.hip", "bn_multi.hip", "pool.hip", "heads.hip", "stft.hip", "engine.hip", "train_ops.hip", "frames.hip"]
+# -amdgpu-mfma-vgpr-form: the MFMA accumulators live in VGPRs instead of AGPRs.  With AGPR accumulators the compiler
+# copied every accumulator register AGPR -> VGPR -> AGPR once per K-loop iteration around some loop shapes (the split-K
+# tile kernel: 32 copies per 16 MFMAs; the LDS-DMA and LDS-halo kernels likewise) -- VALU instructions on the port the
+# fp32 MFMA shares, plus an MFMA pipeline drain in front of each copy block -- and rounded the VGPR / AGPR halves up
+# separately (scripts/isa_scan.py: fewer registers for most instantiations, one more wave per SIMD for a dozen of them).
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
+         "-mllvm", "-amdgpu-mfma-vgpr-form",
          "-I" + os.path.join(os.path.dirname(HERE), "include")]
 if os.environ.get("TBN_DIAG") == "1":         # timing-diagnostic build (engine can skip kernel groups; results invalid)
     FLAGS.append("-DTBN_DIAG=1")

@@ -184,6 +184,10 @@ int tbn_conv2d_fwd(const float* in, int in_ld, const float* weight, const float*
   TBN_REQUIRE(epilogue >= 0 && epilogue <= 2, "conv2d_fwd: bad epilogue");
   TBN_REQUIRE(epilogue != CONV_EPI_STATS || stat_partial, "conv2d_fwd: stats epilogue needs stat_partial");
   TBN_REQUIRE(epilogue != CONV_EPI_EVAL || (scale && shift), "conv2d_fwd: eval epilogue needs scale/shift");
+  // the split-K tile kernel writes one statistics row per 32*mt output rows, tbn_conv2d_stat_tiles() counts 128-row tiles:
+  // only the explicit-tile entry point (tbn_conv2d_fwd_tile / tbn_conv_launch) may combine the two
+  TBN_REQUIRE(!(epilogue == CONV_EPI_STATS && (flags & CONV_FLAG_SK4)),
+              "conv2d_fwd: the split-K tile variant with the statistics epilogue needs an explicit tile (tbn_conv2d_fwd_tile)");
   ConvP p;
   conv_geom(&p, n, h, w, cin, cout, ksize, stride, pad);
   p.in = in;
@@ -254,6 +258,94 @@ int tbn_conv2d_dgrad(const float* dout, int dout_ld, const float* weight, float*
   p.seg[0].ld = din_ld;
   p.seg[0].col_begin = 0;
   return tbn_launch_conv(p, 0, 0, 0, st);
+}
+
+// ---- descriptor form (test / tuning aid): every variant / tile / epilogue the engine can launch
+static int desc_to_convp(const tbn_conv_desc* d, float* workspace, hipStream_t st, ConvP* pp) {
+  ConvP& p = *pp;
+  TBN_REQUIRE(d && d->in && d->weight && d->out, "conv_launch: null pointer");
+  if (!d->dgrad) {
+    TBN_REQUIRE(d->epilogue >= 0 && d->epilogue <= 2, "conv_launch: bad epilogue");
+    TBN_REQUIRE(d->epilogue != CONV_EPI_STATS || d->stat_partial, "conv_launch: stats epilogue needs stat_partial");
+    TBN_REQUIRE(d->epilogue != CONV_EPI_EVAL || (d->scale && d->shift), "conv_launch: eval epilogue needs scale/shift");
+    TBN_REQUIRE(d->nred == 0, "conv_launch: the fused BN-backward reduce belongs to a data gradient");
+    conv_geom(&p, d->n, d->h, d->w, d->cin, d->cout, d->ksize, d->stride, d->pad);
+    p.in = d->in;
+    p.in_ld = d->in_ld;
+    p.wt = d->weight;
+    p.bias = d->bias;
+    p.scale = d->scale;
+    p.shift = d->shift;
+    p.stat_partial = d->stat_partial;
+    p.mode = d->epilogue;
+  } else {
+    TBN_REQUIRE(workspace != nullptr, "conv_launch: a data gradient needs the flipped-weight workspace");
+    TBN_REQUIRE(d->epilogue == 0 && d->nred >= 0 && d->nred <= TBN_CONV_MAXSEG, "conv_launch: data gradient: epilogue 0, nred <= 4");
+    TBN_TRY(tbn_launch_weight_flip_transpose(d->weight, workspace, d->cout, d->ksize * d->ksize, d->cin, st));
+    const int oh = (d->h + 2 * d->pad - d->ksize) / d->stride + 1, ow = (d->w + 2 * d->pad - d->ksize) / d->stride + 1;
+    memset(&p, 0, sizeof(p));
+    p.in = d->in;
+    p.in_ld = d->in_ld;
+    p.wt = workspace;
+    p.N = d->n;
+    p.H = oh;
+    p.W = ow;
+    p.OH = d->h;
+    p.OW = d->w;
+    p.Cin = d->cout;
+    p.Cout = d->cin;
+    p.R = p.S = d->ksize;
+    p.stride = 1;
+    p.pad = d->ksize - 1 - d->pad;
+    p.up = d->stride;
+    p.M = d->n * d->h * d->w;
+    p.K = d->ksize * d->ksize * d->cout;
+    p.mode = CONV_EPI_PLAIN;
+    p.nred = d->nred;
+    p.red_chan = d->red_stats_stride;
+    for (int i = 0; i < d->nred; ++i) {
+      TBN_REQUIRE(d->red[i].partial && d->red_stats, "conv_launch: reduce segment %d incomplete", i);
+      p.red[i].y = d->red[i].y;
+      p.red[i].y_ld = d->red[i].y_ld;
+      p.red[i].partial = d->red[i].partial;
+      p.red[i].stats = d->red_stats;
+      p.red[i].col_begin = d->red[i].col_begin;
+      p.red[i].C = d->red[i].channels;
+      p.red[i].c_off = d->red[i].stat_offset;
+    }
+  }
+  p.flags = d->flags;
+  p.stages = d->stages;
+  p.nseg = 1;
+  p.seg[0].ptr = d->out;
+  p.seg[0].ld = d->out_ld;
+  p.seg[0].col_begin = 0;
+  return TBN_OK;
+}
+
+int tbn_conv_partial_rows(const tbn_conv_desc* d, int mt, int pair) {
+  if (!d || mt < 1) return 0;
+  const int rows = ((d->flags & CONV_FLAG_SK4) && !pair ? 32 : 128) * mt;
+  if (d->dgrad) return tbn_conv_red_rows(d->n, d->h, d->w, d->stride, rows);
+  const int oh = (d->h + 2 * d->pad - d->ksize) / d->stride + 1, ow = (d->w + 2 * d->pad - d->ksize) / d->stride + 1;
+  return cdiv(d->n * oh * ow, rows);
+}
+
+int tbn_conv_launch(const tbn_conv_desc* d, int mt, int nt, float* workspace, void* stream) {
+  ConvP p;
+  TBN_TRY(desc_to_convp(d, workspace, (hipStream_t)stream, &p));
+  // partial-sum epilogues write one row per M tile: the caller sized the buffers for an explicit tile
+  TBN_REQUIRE(((d->dgrad ? d->nred == 0 : d->epilogue != CONV_EPI_STATS)) || (mt >= 1 && nt >= 1),
+              "conv_launch: partial-sum epilogues need an explicit tile");
+  return tbn_launch_conv(p, 0, mt, nt, (hipStream_t)stream);
+}
+
+int tbn_conv_launch_pair(const tbn_conv_desc* a, const tbn_conv_desc* b, int variant, int mt, int nt,
+                         float* workspace_a, float* workspace_b, void* stream) {
+  ConvP pa, pb;
+  TBN_TRY(desc_to_convp(a, workspace_a, (hipStream_t)stream, &pa));
+  TBN_TRY(desc_to_convp(b, workspace_b, (hipStream_t)stream, &pb));
+  return tbn_launch_conv_pair(pa, pb, variant, mt, nt, (hipStream_t)stream);
 }
 
 static void wgrad_geom(WgradP* wp, int n, int h, int w, int cin, int cout, int k, int stride, int pad) {
@@ -343,6 +435,38 @@ int tbn_bn_relu_train_bwd(const float* dz, int dz_ld, const float* y, int p, int
   TBN_TRY(tbn_launch_bn_bwd_finalize(workspace, parts, p, c, scale, save_mean, save_rstd, coef, dgamma, dbeta, nullptr,
                                      st));
   return tbn_launch_bn_bwd_apply(&s, 1, y, p, c, scale, shift, coef, dy, st);
+}
+
+// ---- training BN + ReLU + max pool in one pass (the fused stem form of the engine)
+int tbn_bn_relu_maxpool_train_fwd(const float* y, int n, int h, int w, int c, const float* gamma, const float* beta,
+                                  float* running_mean, float* running_var, float momentum, float eps, float* save_mean,
+                                  float* save_rstd, float* scale, float* shift, float* pooled, int pooled_ld,
+                                  uint8_t* argmax, int oh, int ow, int stride, int pad, float* workspace, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  TBN_REQUIRE(y && pooled && argmax && workspace, "bn_relu_maxpool_train_fwd: null pointer");
+  const int p = n * h * w;
+  int parts = 0;
+  TBN_TRY(tbn_launch_bn_stats(y, c, p, c, workspace, &parts, st));
+  TBN_TRY(tbn_launch_bn_finalize(workspace, parts, p, c, gamma, beta, nullptr, running_mean, running_var, momentum, eps,
+                                 save_mean, save_rstd, scale, shift, st));
+  return tbn_launch_bn_apply_maxpool(y, n, h, w, c, scale, shift, pooled, pooled_ld, argmax, oh, ow, stride, pad, st);
+}
+
+int tbn_bn_relu_maxpool_train_bwd(const float* dpooled, int dpooled_ld, const uint8_t* argmax, const float* y, int n, int h,
+                                  int w, int c, int oh, int ow, int stride, int pad, const float* save_mean,
+                                  const float* save_rstd, const float* scale, const float* shift, float* dy,
+                                  float* dgamma, float* dbeta, float* workspace, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  TBN_REQUIRE(dpooled && argmax && y && dy && workspace, "bn_relu_maxpool_train_bwd: null pointer");
+  const int p = n * h * w;
+  const int parts = tbn_bn_bwd_pooled_parts(n, h, w, c, stride, pad);
+  TBN_REQUIRE(parts <= tbn_bn_bwd_parts(p, c), "bn_relu_maxpool_train_bwd: workspace sized by tbn_bn_workspace_floats is too small");
+  float* coef = workspace + (size_t)tbn_bn_bwd_parts(p, c) * 2 * c;
+  TBN_TRY(tbn_launch_bn_bwd_reduce_pooled(dpooled, dpooled_ld, argmax, n, h, w, oh, ow, stride, pad, y, c, scale, shift,
+                                          save_mean, save_rstd, workspace, st));
+  TBN_TRY(tbn_launch_bn_bwd_finalize(workspace, parts, p, c, scale, save_mean, save_rstd, coef, dgamma, dbeta, nullptr, st));
+  return tbn_launch_bn_bwd_apply_pooled(dpooled, dpooled_ld, argmax, n, h, w, oh, ow, stride, pad, y, c, scale, shift, coef,
+                                        dy, st);
 }
 
 // ---- pooling

@@ -636,7 +636,8 @@ __device__ __forceinline__ void lds_dma16(i32x4 rsrc, unsigned lds_dst, unsigned
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
                :
                : "s"(lds_dst), "v"(voff), "s"(rsrc), "s"(soff)
-               : "memory");
+               : "memory");   // (m0 cannot be named as a clobber: clang rejects it as a reserved register; nothing else in this
+                              //  kernel keeps a value in M0 -- no readlane / movrel / LDS-direct uses)
 }
 
 template <int MT, int NT, int EPI, bool RED>
@@ -694,29 +695,30 @@ __device__ __forceinline__ void conv_dma_body(const ConvP& p, const int bid, flo
   // (the low 32 bits of a generic pointer into LDS are the LDS byte offset)
   const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)lds_b);
 
+  // unit-stride launches only (no parity phases): tap t's weights start at K offset t * Cin, so the weight-row byte
+  // offset of a K-step is a plain scalar counter
   int l_tap = 0, l_c0 = 0;
-  unsigned l_toff = (unsigned)p.tap_off[0], l_koff = (unsigned)p.tap_koff[0] * 4u;
+  unsigned l_toff = (unsigned)p.tap_off[0], k_byte = 0u;
   unsigned a_cur[AR];
   auto issue_tiles = [&](int stage) {
     if (l_c0 == 0) {
 #pragma unroll
       for (int i = 0; i < AR; ++i) a_cur[i] = ((a_mask[i] >> l_tap) & 1u) ? a_off[i] + l_toff : TBN_OOB;
     }
+    // (the loop-carried counters end up in VGPRs -- SIFixSGPRCopies -- and an "s" asm operand is not legalised: readfirstlane)
     const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(l_c0 * 4);
     const unsigned st = lds0 + (unsigned)(stage * TILE_B);
 #pragma unroll
     for (int i = 0; i < AR; ++i) lds_dma16(in_rsrc, st + (unsigned)((wv * AR + i) * 1024), a_cur[i], soff);
-    const unsigned koff = (unsigned)__builtin_amdgcn_readfirstlane((int)l_koff + l_c0 * 4);
+    const unsigned koff = (unsigned)__builtin_amdgcn_readfirstlane((int)k_byte);
 #pragma unroll
     for (int i = 0; i < NT; ++i) lds_dma16(wt_rsrc, st + (unsigned)(BM * 128 + (wv + 4 * i) * 1024), b_voff[i], koff);
+    k_byte += 128u;
     l_c0 += 32;
     if (l_c0 == p.Cin) {
       l_c0 = 0;
       ++l_tap;
-      if (l_tap < p.ntaps) {
-        l_toff = (unsigned)p.tap_off[l_tap];
-        l_koff = (unsigned)p.tap_koff[l_tap] * 4u;
-      }
+      if (l_tap < p.ntaps) l_toff = (unsigned)p.tap_off[l_tap];
     }
   };
 
@@ -999,8 +1001,23 @@ __global__ __launch_bounds__(256) void conv_igemm_phases_kernel(ConvPhases q) {
 // waves of a workgroup reduces a different quarter of the workgroup's pixel range over the same
 // (32*MT co) x (32*NT ci) tile of one filter tap; the 4 partial tiles are summed through LDS
 // in fixed order (deterministic), then stored to `out` (final dW or a split-K slab).
-template <int MT, int NT, bool ROWMODE>
+// MODE 0: any filter / stride / pad (the x row of an output pixel is found from its in-frame index, see below);
+//      1: the packed-row stem (ROWMODE of conv_igemm_body: the "Cin" columns are R runs of `rl` floats of a physically
+//         zero-padded image, no masks);  2: pointwise (1x1 / stride 1 / pad 0, and the Linear layers): x row = dy row.
+// VALU diet (the fp32 MFMA shares its issue port with the VALU: every VALU instruction in this loop is ~4 of an MFMA's 64
+// cycles, and a (64-row) step of a 64 x 64 tile is only 32 MFMAs).  A lane owns ONE pixel row of the 16-row step
+// (row = l >> 2) and the float4 columns {q, q+4, q+8, ...} (q = l & 3).  Round 2 decoded the row from scratch every
+// step (two 64-bit magic divisions, bounds compares, one select per load for ragged column tiles: 38-46 VALU per
+// step, 1.3 per MFMA for the 64 x 64 tile, 2.4 for 64 x 32).  Now the row state advances incrementally:
+//   * dy: byte offset += 64 rows; rows >= M lie beyond the buffer extent (the hardware returns zeros), a split never
+//     ends inside a step (rows_per_split is a multiple of 64), column offsets ride in the instruction's immediate;
+//     ragged column tiles read finite neighbours / zeros beyond the extent into accumulator rows that are never stored;
+//   * x: the in-frame output pixel index pp (+= 64 mod OH*OW with one conditional wrap, the frame byte base follows)
+//     gives (oy, ox) with ONE v_mul_hi (exact: pp * OW < 2^32), the input pixel with 24-bit multiply-adds;
+//   pointwise layers need none of it (2 VALU per step), the general form 15, the stem 11 + one add per load.
+template <int MT, int NT, int MODE>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
+  constexpr bool ROWMODE = (MODE == 1);
   constexpr int WA = 32 * MT + 4, WB = 32 * NT + 4;  // LDS pitches (a +16 pad removes the write conflicts but gains nothing)
   constexpr int KR = 16;                             // pixel rows per wave step
   constexpr int TILE = KR * (WA + WB);
@@ -1035,7 +1052,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
     s = tap - r * p.S;
   }
   const int pbeg = split * p.rows_per_split;
-  const int pend = min(p.M, pbeg + p.rows_per_split);
 
   // K-split accumulators per sub-tile so that >= 4 independent accumulators rotate (see the main loop)
   constexpr int KS = (MT * NT >= 4) ? 1 : (MT * NT == 1 ? 4 : 2);
@@ -1049,62 +1065,66 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][j][q][e] = 0.f;
 
-  // VALU diet (the fp32 MFMA shares the VALU lanes: every VALU op costs MFMA time).  Lane l owns ONE pixel
-  // row of the 16-row step (row = l >> 2) and the float4 columns {q, q+4, q+8, ...} (q = l & 3): the row is
-  // decoded once per lane per step and the column stride rides in the load's immediate offset; 4 lanes x 16 B
-  // still make 64-B contiguous requests per row.
   constexpr int AI = 2 * MT, BI = 2 * NT;
   float4 ra[AI], rb[BI];
   const int lrow16 = lane >> 2, lq = lane & 3;
-  const bool a_full = (co0 + 32 * MT <= p.Cout), b_full = (ci0 + 32 * NT <= p.Cin);
   const i32x4 dy_rsrc = make_rsrc(p.dy, p.dy_bytes);
   const i32x4 x_rsrc = make_rsrc(p.x, p.x_bytes);
-  // ROWMODE (the stem, see conv_igemm_body): the `Cin` columns are the packed K of a pixel -- R runs of `rl` floats,
-  // one per row of the zero-padded space-to-depth image.  A lane's columns are fixed: their (run, offset) byte
-  // displacements from the pixel's first run are computed once; the loop only decodes the pixel.
+  // row state of this lane: row m = pbeg + (4 it + wave) * 16 + lrow16 in step `it`
+  const unsigned m0 = (unsigned)(pbeg + wave * KR + lrow16);
+  unsigned dyo = (m0 * (unsigned)p.dy_ld + (unsigned)(co0 + lq * 4)) * 4u;
+  const unsigned dy_step = (unsigned)(4 * KR * p.dy_ld) * 4u;
+  unsigned xo = 0, pp = 0, fb = 0;
   unsigned rm_off[BI];
-  if (ROWMODE) {
+  if (MODE == 2) {
+    xo = (m0 * (unsigned)p.x_ld + (unsigned)(ci0 + lq * 4)) * 4u;
+  } else {
+    const uint32_t n = fdiv(m0, p.div_ohw);
+    pp = m0 - n * p.div_ohw.d;
+    fb = n * p.frame_bytes + (ROWMODE ? 0u : (unsigned)(ci0 + lq * 4) * 4u);
+    if (ROWMODE) {
+      // this lane's columns are fixed: their (run, offset) byte displacements from the pixel's first run, once
 #pragma unroll
-    for (int k = 0; k < BI; ++k) {
-      const int cc = ci0 + lq * 4 + 16 * k;
-      const uint32_t f = (uint32_t)cc >> 2, t = fdiv(f, p.div_rl4);
-      rm_off[k] = (t * (uint32_t)(p.W * p.cp) + (f - t * p.div_rl4.d) * 4u) * 4u;
+      for (int k = 0; k < BI; ++k) {
+        const int cc = ci0 + lq * 4 + 16 * k;
+        const uint32_t f = (uint32_t)cc >> 2, t = fdiv(f, p.div_rl4);
+        rm_off[k] = (t * (uint32_t)(p.W * p.cp) + (f - t * p.div_rl4.d) * 4u) * 4u;
+      }
     }
   }
-  auto load_tiles = [&](int row0) {
-    const int m = row0 + lrow16;
-    const bool row_ok = m < pend;
-    {
-      const unsigned base = row_ok ? ((unsigned)m * (unsigned)p.dy_ld + (unsigned)(co0 + lq * 4)) * 4u : TBN_OOB;
+  const unsigned x_step = (unsigned)(4 * KR * p.x_ld) * 4u;
+  const int tap_y = r - p.pad, tap_x = s - p.pad;
+  const unsigned xld4 = (unsigned)p.x_ld * 4u;
+  auto load_tiles = [&]() {
 #pragma unroll
-      for (int k = 0; k < AI; ++k) {
-        const bool ok = a_full || (co0 + lq * 4 + 16 * k < p.Cout);
-        ra[k] = buf_load4(dy_rsrc, ok ? base + 64u * k : TBN_OOB);
-      }
-    }
-    const uint32_t n = fdiv((uint32_t)m, p.div_ohw);
-    const uint32_t rem = (uint32_t)m - n * p.div_ohw.d;
-    const uint32_t oy = fdiv(rem, p.div_ow);
-    const uint32_t ox = rem - oy * p.div_ow.d;
-    const int iy = (int)oy * p.stride - p.pad + r;
-    const int ix = (int)ox * p.stride - p.pad + s;
-    if (!ROWMODE) {
-      const bool okrow = row_ok && ((unsigned)iy < (unsigned)p.H) && ((unsigned)ix < (unsigned)p.W);
-      const unsigned base =
-          okrow ? (((n * p.H + iy) * p.W + ix) * (unsigned)p.x_ld + (unsigned)(ci0 + lq * 4)) * 4u : TBN_OOB;
+    for (int k = 0; k < AI; ++k) ra[k] = buf_load4(dy_rsrc, dyo + 64u * k);
+    dyo += dy_step;
+    if (MODE == 2) {
 #pragma unroll
-      for (int k = 0; k < BI; ++k) {
-        const bool ok = b_full || (ci0 + lq * 4 + 16 * k < p.Cin);
-        rb[k] = buf_load4(x_rsrc, ok ? base + 64u * k : TBN_OOB);
-      }
+      for (int k = 0; k < BI; ++k) rb[k] = buf_load4(x_rsrc, xo + 64u * k);
+      xo += x_step;
     } else {
-      // no masks: the border is in the image; a row >= pend starts at 2^31 and stays out of range -> zeros
-      const unsigned base = row_ok ? ((n * p.H + iy) * p.W + ix) * (unsigned)p.cp * 4u : TBN_OOB;
+      const unsigned oy = p.mul_ow != 0u ? __umulhi(pp, p.mul_ow) : pp;   // (OW == 1: the magic number 2^32 does not fit)
+      const unsigned ox = pp - __umul24(oy, (unsigned)p.OW);
+      if (MODE == 0) {
+        const unsigned iy = __umul24(oy, (unsigned)p.stride) + (unsigned)tap_y;   // wraps below zero: fails the unsigned compare
+        const unsigned ix = __umul24(ox, (unsigned)p.stride) + (unsigned)tap_x;
+        const bool ok = (iy < (unsigned)p.H) && (ix < (unsigned)p.W);
+        const unsigned off = fb + __umul24(__umul24(iy, (unsigned)p.W) + ix, xld4);
+        const unsigned voff = ok ? off : TBN_OOB;
 #pragma unroll
-      for (int k = 0; k < BI; ++k) {
-        const bool ok = b_full || (ci0 + lq * 4 + 16 * k < p.Cin);
-        rb[k] = buf_load4(x_rsrc, ok ? base + rm_off[k] : TBN_OOB);
+        for (int k = 0; k < BI; ++k) rb[k] = buf_load4(x_rsrc, voff + 64u * k);
+      } else {
+        // no masks: the border is in the image; rows >= M start beyond the image extent -> zeros
+        const unsigned off = fb + __umul24(oy, p.row_step) + __umul24(ox, p.col_step);
+#pragma unroll
+        for (int k = 0; k < BI; ++k) rb[k] = buf_load4(x_rsrc, off + rm_off[k]);
       }
+      // 64 rows on: in-frame index and frame base (64 = q64 * OH*OW + r64)
+      pp += p.r64;
+      const bool wrap = pp >= p.div_ohw.d;
+      pp = wrap ? pp - p.div_ohw.d : pp;
+      fb += wrap ? p.fb_hi : p.fb_lo;
     }
   };
   auto store_tiles = [&]() {
@@ -1118,11 +1138,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
   // needs NO workgroup barrier: the four waves run decoupled (wave_barrier only pins the compiler's order).
   const int nsteps = (p.rows_per_split + 4 * KR - 1) / (4 * KR);
   const int lrow = lane & 31, lhalf = lane >> 5;
-  load_tiles(pbeg + wave * KR);
+  load_tiles();
   for (int it = 0; it < nsteps; ++it) {
     if (!WABL(2) || it == 0) store_tiles();
     __builtin_amdgcn_wave_barrier();
-    if (it + 1 < nsteps && !WABL(1)) load_tiles(pbeg + ((it + 1) * 4 + wave) * KR);
+    if (it + 1 < nsteps && !WABL(1)) load_tiles();
     if (WABL(4)) continue;
     // Fragments of k-pair kp+1 are read while k-pair kp multiplies (two register sets; the sched_group_barrier
     // chain pins the DS-read group / MFMA group alternation).  Consecutive MFMAs rotate over FOUR independent
@@ -1465,17 +1485,20 @@ static int launch_conv_tiles(ConvP& p, int rowmode, int mt, int nt, hipStream_t 
 static int conv_prepare(ConvP& p, int rowmode, int* single) {
   if (rowmode) {
     // R contiguous runs of Cin floats per output pixel, read from a physically zero-padded image without masks
-    p.K = p.R * p.Cin;
-    TBN_REQUIRE(p.K % 32 == 0 && p.Cin % 4 == 0 && p.cp % 4 == 0 && p.Cin % p.cp == 0 && p.pad == 0 && p.up == 1,
-                "conv: packed-row mode needs K = R*Cin (%d) % 32 == 0, Cin / cp multiples of 4, pad 0", p.K);
-    TBN_REQUIRE((p.OH - 1) * p.stride + p.R <= p.H && (p.OW - 1) * p.stride + p.Cin / p.cp <= p.W,
+    // K = the R runs, padded to a multiple of 32 with the first floats of a further run (zero weights; the caller's
+    // image holds that row)
+    const int kruns = cdiv(cdiv(p.R * p.Cin, 32) * 32, p.Cin);   // runs the padded K touches
+    p.K = cdiv(p.R * p.Cin, 32) * 32;
+    TBN_REQUIRE(p.Cin % 4 == 0 && p.cp >= 1 && p.pad == 0 && p.up == 1,
+                "conv: packed-row mode needs run lengths in multiples of 4 floats, pad 0 (K = %d)", p.K);
+    TBN_REQUIRE((p.OH - 1) * p.stride + kruns <= p.H && (p.OW - 1) * p.stride + cdiv(p.Cin, p.cp) <= p.W,
                 "conv: packed-row mode reads beyond the padded image (%dx%d)", p.H, p.W);
   } else {
     TBN_REQUIRE(p.K % 32 == 0 && p.Cin % 32 == 0, "conv: K (%d) and per-tap Cin (%d) must be multiples of 32", p.K,
                 p.Cin);
     TBN_REQUIRE(p.R <= 3 && p.S <= 3, "conv: filters larger than 3x3 take the packed-row (stem) path");
   }
-  TBN_REQUIRE(p.in_ld % 4 == 0 && p.nseg >= 1 && p.nseg <= TBN_CONV_MAXSEG, "conv: bad in_ld %d / nseg %d", p.in_ld,
+  TBN_REQUIRE((rowmode || p.in_ld % 4 == 0) && p.nseg >= 1 && p.nseg <= TBN_CONV_MAXSEG, "conv: bad in_ld %d / nseg %d", p.in_ld,
               p.nseg);
   TBN_REQUIRE(p.nred >= 0 && p.nred <= TBN_CONV_MAXSEG && (p.nred == 0 || (p.mode == CONV_EPI_PLAIN && !rowmode)),
               "conv: the fused BN-backward reduce belongs to a plain (data-gradient) epilogue");
@@ -1755,9 +1778,9 @@ int tbn_launch_conv_pair(ConvP a, ConvP b, int variant, int mt, int nt, hipStrea
   return TBN_OK;
 }
 
-template <int MT, int NT, bool RM>
+template <int MT, int NT, int MODE>
 static void launch_wgrad(const WgradP& p, int blocks, hipStream_t st) {
-  hipLaunchKernelGGL((conv_wgrad_kernel<MT, NT, RM>), dim3(blocks), dim3(256), 0, st, p);
+  hipLaunchKernelGGL((conv_wgrad_kernel<MT, NT, MODE>), dim3(blocks), dim3(256), 0, st, p);
 }
 
 // 32-column sub-tiles per workgroup along one dimension: 3 for 96 (and other odd multiples of 96), else 2 when the
@@ -1802,7 +1825,12 @@ void tbn_wgrad_plan(int M, int Cout, int Cin, int taps, int* mt, int* nt, int* s
     return;
   }
 #endif
-  const int occ = (*mt == 3 || *nt == 3 || (*mt == 5 && *nt > 1)) ? 1 : 2;   // 248+144 / 184+96 registers vs 128+64
+  int occ = (*mt == 3 || *nt == 3 || (*mt == 5 && *nt > 1)) ? 1 : 2;   // workgroups per CU the cost model assumes
+  {
+    // experiment knob (A/B runs only): with VGPR-form accumulators the 64 x 64 and smaller tiles fit FOUR workgroups per CU
+    static const int occ_env = getenv("TBN_WGRAD_OCC") ? atoi(getenv("TBN_WGRAD_OCC")) : 0;
+    if (occ_env > 0 && occ == 2) occ = occ_env;
+  }
   const int slots = 256 * occ;
   const double step_us = *mt * *nt * 8 * 64 / 2.4e3 * occ;  // 8 k-pairs x MT*NT MFMAs of 64 cycles, SIMD shared by occ waves
   const double slab_mb = (double)Cout * Cin * taps * 4e-6;
@@ -1833,12 +1861,14 @@ size_t tbn_wgrad_workspace_floats(int M, int Cout, int Cin, int taps) {
 }
 
 int tbn_launch_wgrad(WgradP p, int rowmode, float* dw, float* workspace, hipStream_t st) {
-  TBN_REQUIRE(p.Cin % 4 == 0 && p.Cout % 4 == 0 && p.dy_ld % 4 == 0 && p.x_ld % 4 == 0,
+  TBN_REQUIRE(p.Cin % 4 == 0 && p.Cout % 4 == 0 && p.dy_ld % 4 == 0 && (rowmode || p.x_ld % 4 == 0),
               "wgrad: channel counts / pitches must be multiples of 4");
   TBN_REQUIRE(p.M > 0, "wgrad: empty problem");
   {
-    const size_t xb = (size_t)p.N * p.H * p.W * (rowmode ? p.cp : p.x_ld) * sizeof(float);
-    const size_t db = (size_t)p.M * p.dy_ld * sizeof(float);
+    // exact extents: the kernel relies on the hardware range check for rows >= M and for ragged column tiles
+    const size_t xb = rowmode ? (size_t)p.N * p.H * p.W * p.cp * sizeof(float)
+                              : (((size_t)p.N * p.H * p.W - 1) * p.x_ld + p.Cin) * sizeof(float);
+    const size_t db = (((size_t)p.M - 1) * p.dy_ld + p.Cout) * sizeof(float);
     TBN_REQUIRE(xb < (1ull << 31) && db < (1ull << 31), "wgrad: operand extent >= 2 GiB (process the frames in chunks)");
     p.x_bytes = (unsigned)xb;
     p.dy_bytes = (unsigned)db;
@@ -1849,9 +1879,10 @@ int tbn_launch_wgrad(WgradP p, int rowmode, float* dw, float* workspace, hipStre
   if (const char* e = getenv("TBN_WGRAD_NT")) p.nt = atoi(e);
 #endif
   if (rowmode) {
-    TBN_REQUIRE(p.taps == 1 && p.pad == 0 && p.rl > 0 && p.rl % 4 == 0 && p.cp % 4 == 0 && p.rl % p.cp == 0 && p.Cin % p.rl == 0,
-                "wgrad: packed-row mode needs taps 1, pad 0, Cin = R * rl, rl / cp multiples of 4");
-    TBN_REQUIRE((p.OH - 1) * p.stride + p.Cin / p.rl <= p.H && (p.OW - 1) * p.stride + p.rl / p.cp <= p.W,
+    TBN_REQUIRE(p.taps == 1 && p.pad == 0 && p.rl > 0 && p.rl % 4 == 0 && p.cp >= 1 && p.Cin % p.rl == 0,
+                "wgrad: packed-row mode needs taps 1, pad 0, Cin = R * rl, rl a multiple of 4");
+    // (the last column tile may reach into one further run: finite image data into accumulator columns never stored)
+    TBN_REQUIRE((p.OH - 1) * p.stride + p.Cin / p.rl <= p.H && (p.OW - 1) * p.stride + cdiv(p.rl, p.cp) <= p.W,
                 "wgrad: packed-row mode reads beyond the padded image (%dx%d)", p.H, p.W);
   }
   p.div_rl4 = make_fastdiv((uint32_t)(rowmode ? p.rl / 4 : 1));
@@ -1863,23 +1894,42 @@ int tbn_launch_wgrad(WgradP p, int rowmode, float* dw, float* workspace, hipStre
   p.rows_per_split = rps;
   p.div_ohw = make_fastdiv((uint32_t)(p.OH * p.OW));
   p.div_ow = make_fastdiv((uint32_t)p.OW);
+  // incremental row addressing (see the kernel): 64 rows per step
+  TBN_REQUIRE(rps % 64 == 0, "wgrad: rows per split must be a multiple of 64");
+  const int mode = rowmode ? 1 : ((p.taps == 1 && p.stride == 1 && p.pad == 0 && p.OH == p.H && p.OW == p.W) ? 2 : 0);
+  {
+    const uint64_t ohw = (uint64_t)p.OH * p.OW;
+    TBN_REQUIRE(ohw * p.OW < (1ull << 32) && p.H < (1 << 23) && p.W < (1 << 23) && (uint64_t)p.H * p.W < (1ull << 24) &&
+                    (uint64_t)p.x_ld * 4 < (1ull << 24),
+                "wgrad: feature map too large for the 24-bit row arithmetic");
+    p.mul_ow = p.OW == 1 ? 0u : (unsigned)(((1ull << 32) + p.OW - 1) / p.OW);   // 0: oy = pp (one-column maps)
+    p.r64 = (unsigned)(64 % ohw);
+    p.frame_bytes = (unsigned)((size_t)p.H * p.W * (rowmode ? p.cp : p.x_ld) * sizeof(float));
+    p.fb_lo = (unsigned)(64 / ohw) * p.frame_bytes;
+    p.fb_hi = p.fb_lo + p.frame_bytes;
+    p.row_step = (unsigned)((size_t)p.stride * p.W * p.cp * sizeof(float));
+    p.col_step = (unsigned)((size_t)p.stride * p.cp * sizeof(float));
+    TBN_REQUIRE(!rowmode || (p.row_step < (1u << 24) && p.col_step < (1u << 24)), "wgrad: padded image row too long");
+  }
   TBN_REQUIRE(splits == 1 || workspace != nullptr, "wgrad: split-K needs a workspace");
   p.out = splits > 1 ? workspace : dw;
   const int blocks = p.tiles_co * p.tiles_ci * p.taps * splits;
   if (p.alg_flops <= 0.0) p.alg_flops = 2.0 * p.M * (double)p.Cout * p.K;
   {
     char nm[64];
-    snprintf(nm, sizeof(nm), "conv_wgrad_kernel<%d, %d, %s>", mt, nt, rowmode ? "true" : "false");
+    snprintf(nm, sizeof(nm), "conv_wgrad_kernel<%d, %d, %d>", mt, nt, mode);
     // algorithmic bytes: dy and x read once, dW written once (split-K slabs are overhead, not counted)
     tbn_prof_begin(nm, p.alg_flops, st,
                    4.0 * ((double)p.M * p.Cout + (double)p.N * p.H * p.W * (rowmode ? p.cp : p.Cin) + (double)p.Cout * p.K));
   }
 #define TBN_CASE(MTv, NTv)                                          \
   if (mt == MTv && nt == NTv) {                                     \
-    if (rowmode)                                                    \
-      launch_wgrad<MTv, NTv, true>(p, blocks, st);                  \
+    if (mode == 1)                                                  \
+      launch_wgrad<MTv, NTv, 1>(p, blocks, st);                     \
+    else if (mode == 2)                                             \
+      launch_wgrad<MTv, NTv, 2>(p, blocks, st);                     \
     else                                                            \
-      launch_wgrad<MTv, NTv, false>(p, blocks, st);                 \
+      launch_wgrad<MTv, NTv, 0>(p, blocks, st);                     \
   } else
   TBN_CASE(1, 1) TBN_CASE(1, 2) TBN_CASE(1, 3) TBN_CASE(2, 1) TBN_CASE(2, 2) TBN_CASE(2, 3) TBN_CASE(3, 1) TBN_CASE(3, 2)
   TBN_CASE(3, 3) TBN_CASE(5, 1) TBN_CASE(5, 2) {

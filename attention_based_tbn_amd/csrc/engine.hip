@@ -72,14 +72,22 @@ struct Conv {   // one GEMM: up to four parts that read the same input (adjacent
   size_t w_off, c_off;
   size_t y_off;                 // training: raw conv output (P x cout); becomes dy in place during backward
   int slot = 0;                 // forward statistics scratch slot
-  int mt, nt, stages = 0;       // forward tile / LDS stages (0 = default)
-  int d_mt, d_nt, d_stages = 0; // dgrad tile
-  int halo = 0, d_halo = 0;     // 3x3 / stride-1 layers: LDS-halo kernel for the forward / data-gradient GEMM
+  // forward launch choices, PER MODE ([0] eval epilogue, [1] training epilogue): the two modes are tuned separately and a
+  // validation pass at the training shape must not overwrite what training was tuned to (round-2 advisor finding)
+  struct FwdTune {
+    int mt = 1, nt = 1, stages = 0;   // tile / LDS stages (0 = default)
+    int halo = 0;                     // kernel variant: 1 LDS-halo, 2 LDS-DMA, 3 split-K tile
+    bool pair = false;                // sibling pair in one launch (first member holds the decision)
+    int p_variant = 1, p_mt = 1, p_nt = 1;
+    float t = 0.f;                    // autotune: best single-launch time (ms)
+  } ft[2];
+  int d_mt = 1, d_nt = 1, d_stages = 0; // dgrad tile
+  int d_halo = 0;               // kernel variant of the data-gradient GEMM
   // sibling pairing (3x3 | double_3x3_1 of a block: independent GEMMs issued as ONE launch, tbn_launch_conv_pair)
   int pair_next = -1, pair_prev = -1;     // the first member points at the second and vice versa
-  bool pair_fwd = false, pair_dgrad = false;   // decided by the autotuner (first member holds the decision)
-  int pf_variant = 1, pf_mt = 1, pf_nt = 1, pd_variant = 1, pd_mt = 1, pd_nt = 1;
-  float t_fwd = 0.f, t_dgrad = 0.f;       // autotune: best single-launch times (ms)
+  bool pair_dgrad = false;                // decided by the autotuner (first member holds the decision)
+  int pd_variant = 1, pd_mt = 1, pd_nt = 1;
+  float t_dgrad = 0.f;                    // autotune: best single-launch time (ms)
   int w_mt = 0, w_nt = 0;       // wgrad tile (0 = heuristic)
   bool stem;
   bool dgrad_accum;    // dgrad adds into d(inbuf)
@@ -126,6 +134,9 @@ struct tbn_backbone_plan {
   // a filter row = kw = 4 pixels * cp contiguous floats, K = 4 * kw packed (pool.hip, conv_igemm.hip ROWMODE)
   int cp, kw;
   int stem_rows, stem_stride, stem_pad, stem_H, stem_W;
+  // stem_mode 1 ("row runs", many input channels): 7 rows / stride 2 of a zero-bordered NHWC image instead (cp = cin0,
+  // kw = 7*cin0 rounded up to x4); stem_K = multiplied K columns of the forward GEMM (rows * kw rounded up to x32)
+  int stem_mode, stem_K;
   std::vector<Buf> bufs;
   std::vector<Conv> convs;
   std::vector<Pool> pools;
@@ -252,6 +263,24 @@ bool build_graph(tbn_backbone_plan* P) {
   P->stem_pad = 0;
   P->stem_H = (P->H + 1) / 2 + 3;
   P->stem_W = (P->W + 1) / 2 + 3;
+  P->stem_mode = 0;
+  P->stem_K = P->stem_rows * P->kw;
+  {
+    // row runs on the bordered NHWC image when that multiplies fewer K columns (flow: 512 instead of 640; RGB / audio:
+    // the same 192 / 64 -> they keep the space-to-depth form and its 16-B aligned loads)
+    const int rl = (7 * cin0 + 3) / 4 * 4, krows = (7 * rl + 31) / 32 * 32;
+    if (krows < P->stem_K) {
+      const int oh = (P->H + 6 - 7) / 2 + 1, ow = (P->W + 6 - 7) / 2 + 1;
+      P->stem_mode = 1;
+      P->cp = cin0;
+      P->kw = rl;
+      P->stem_rows = 7;
+      P->stem_stride = 2;
+      P->stem_H = 2 * (oh - 1) + 8;
+      P->stem_W = 2 * (ow - 1) + 8;
+      P->stem_K = krows;
+    }
+  }
   P->weight_floats = P->chan_floats = 0;
   const int x0 = add_buf(P, P->H, P->W, cin0);   // logical extent (the stored image is the bordered s2d form: plan_memory)
   // stem
@@ -413,9 +442,7 @@ bool build_graph(tbn_backbone_plan* P) {
   std::vector<int> readers(P->bufs.size(), 0);
   for (auto& c : P->convs) ++readers[c.inbuf];
   for (auto& q : P->pools) ++readers[q.inbuf];
-  // TBN_NO_FUSE_POOL=1 (tests): keep the stem pools as separate kernels so that every z tensor exists in the workspace
-  const bool no_fuse = getenv("TBN_NO_FUSE_POOL") != nullptr && atoi(getenv("TBN_NO_FUSE_POOL")) != 0;
-  for (size_t pi = 0; pi < P->pools.size() && !no_fuse; ++pi) {
+  for (size_t pi = 0; pi < P->pools.size(); ++pi) {
     Pool& q = P->pools[pi];
     if (q.kind != 1 || q.bwd_accum || readers[q.inbuf] != 1 || q.inbuf == P->out_buf) continue;
     for (auto& c : P->convs)
@@ -491,8 +518,10 @@ void plan_memory(tbn_backbone_plan* P) {
   size_t partial = 0, wsplit = 0, wtf = 0;
   for (auto& c : P->convs) {
     const int M = (int)(R * c.outH * c.outW);
-    const int K = c.stem ? P->stem_rows * P->kw : c.k * c.k * c.cin;
-    tbn_conv_pick_tile(M, c.cout, K, &c.mt, &c.nt);
+    const int K = c.stem ? P->stem_K : c.k * c.k * c.cin;
+    tbn_conv_pick_tile(M, c.cout, K, &c.ft[0].mt, &c.ft[0].nt);
+    c.ft[1].mt = c.ft[0].mt;
+    c.ft[1].nt = c.ft[0].nt;
     size_t a = (size_t)cdiv(M, M <= kSk4MaxRows ? 32 : 128) * 2 * c.cout;  // worst case (mt = 1): autotune may pick any tile
     if (a > partial) partial = a;
     for (int k = 0; k < c.nparts; ++k) {
@@ -524,7 +553,7 @@ void plan_memory(tbn_backbone_plan* P) {
   P->wsplit_floats = wsplit;
   P->wt_floats = wtf;
   P->partial_off = take(TBN_BN_MAXL * partial);   // one region per member of a batched BN step
-  P->wpack_off = take((size_t)64 * P->stem_rows * P->kw);
+  P->wpack_off = take((size_t)64 * P->stem_K);
   for (auto& c : P->convs)   // raw / pooled conv output of the pool-after-conv layers: needed in eval too
     for (int k = 0; k < c.nparts; ++k)
       if (c.parts[k].pooled) {
@@ -656,10 +685,21 @@ int tbn_backbone_tensor_info(const tbn_backbone_plan* P, const char* conv_name, 
         *cols = *ld = ib.C;
         return TBN_OK;
       }
+      if (kind == 4) {   // training-mode BN coefficients: mean | rstd | scale | shift rows
+        *offset = (long)(P->stats_off + q.c_off);
+        *rows = 4;
+        *ld = (int)P->chan_floats;
+        return TBN_OK;
+      }
       if (kind == 1) {
         *offset = (long)(q.pooled ? q.y2_off : c.y_off + q.col0);
         *ld = q.pooled ? q.cout : c.cout;
       } else if (kind == 0) {
+        if (c.fuse_pool >= 0) {
+          tbn_set_error("tensor_info: z of '%s' is never written (its max pool runs inside the BN apply): rebuild it "
+                        "from kinds 1 and 4", conv_name);
+          return TBN_ERR_UNSUPPORTED;
+        }
         *offset = (long)(db.off + q.dst_choff);
         *ld = db.C;
       } else {
@@ -669,6 +709,24 @@ int tbn_backbone_tensor_info(const tbn_backbone_plan* P, const char* conv_name, 
       return TBN_OK;
     }
   tbn_set_error("tensor_info: unknown conv '%s'", conv_name);
+  return TBN_ERR_ARG;
+}
+
+int tbn_backbone_launch_info(const tbn_backbone_plan* P, const char* conv_name, int training, int* out16) {
+  TBN_REQUIRE(P && conv_name && out16, "launch_info: null argument");
+  for (auto& c : P->convs)
+    for (int i = 0; i < c.nparts; ++i) {
+      if (c.parts[i].name != conv_name) continue;
+      const Conv::FwdTune& T = c.ft[training ? 1 : 0];
+      const int f[8] = {T.halo, T.mt, T.nt, T.stages, T.pair ? 1 : 0, T.p_variant, T.p_mt, T.p_nt};
+      const int d[8] = {c.d_halo, c.d_mt, c.d_nt, c.d_stages, c.pair_dgrad ? 1 : 0, c.pd_variant, c.pd_mt, c.pd_nt};
+      for (int k = 0; k < 8; ++k) {
+        out16[k] = f[k];
+        out16[8 + k] = (training && c.need_dgrad) ? d[k] : 0;
+      }
+      return TBN_OK;
+    }
+  tbn_set_error("launch_info: unknown conv '%s'", conv_name);
   return TBN_ERR_ARG;
 }
 
@@ -696,7 +754,7 @@ int tbn_backbone_out_shape(const tbn_backbone_plan* P, int* h, int* w, int* c) {
 namespace {
 
 // forward-conv launch parameters of one GEMM (shared by forward and autotune); output segments are set by the caller
-void fill_fwd(const tbn_backbone_plan* P, const Conv& c, float* ws, const float* weight, int R, ConvP* pp) {
+void fill_fwd(const tbn_backbone_plan* P, const Conv& c, int training, float* ws, const float* weight, int R, ConvP* pp) {
   ConvP& p = *pp;
   const Buf& ib = P->bufs[c.inbuf];
   memset(&p, 0, sizeof(p));
@@ -719,7 +777,7 @@ void fill_fwd(const tbn_backbone_plan* P, const Conv& c, float* ws, const float*
     p.Cin = P->kw;
     p.R = P->stem_rows;
     p.S = 1;
-    p.K = P->stem_rows * P->kw;
+    p.K = P->stem_K;
     p.cp = p.in_ld = P->cp;
     p.H = P->stem_H;          // the 4-row / stride-1 conv on the bordered space-to-depth image
     p.W = P->stem_W;
@@ -731,8 +789,8 @@ void fill_fwd(const tbn_backbone_plan* P, const Conv& c, float* ws, const float*
     p.R = p.S = c.k;
     p.K = c.k * c.k * c.cin;
   }
-  p.stages = c.stages;
-  p.halo = c.halo;
+  p.stages = c.ft[training ? 1 : 0].stages;
+  p.halo = c.ft[training ? 1 : 0].halo;
 }
 
 // data-gradient launch parameters of one GEMM: conv of dy with flipped / transposed weights (parity phases for
@@ -850,20 +908,26 @@ int tbn_backbone_forward(const tbn_backbone_plan* P, int training, const float* 
   TBN_REQUIRE(((uintptr_t)workspace & 255) == 0, "backbone_forward: workspace must be 256-B aligned");
   float* ws = (float*)workspace;
   const int R = P->frames;
+  const int tr = training ? 1 : 0;   // index of the forward launch choices (Conv::ft)
   float* mean = ws + P->stats_off;
   float* rstd = mean + P->chan_floats;
   float* scale = rstd + P->chan_floats;
   float* shift = scale + P->chan_floats;
   float* wpack = ws + P->wpack_off;
 
-  TBN_TRY(tbn_launch_nchw_to_s2d_pad(x_nchw, ws + P->x0_off, R, P->cin0, P->H, P->W, st));
-  TBN_TRY(tbn_launch_pack_stem_weight_s2d(prm->weight + P->convs[0].w_off, wpack, 64, P->cin0, st));
+  if (P->stem_mode == 1) {
+    TBN_TRY(tbn_launch_nchw_to_nhwc_pad(x_nchw, ws + P->x0_off, R, P->cin0, P->H, P->W, P->stem_H, P->stem_W, st));
+    TBN_TRY(tbn_launch_pack_stem_weight_rows(prm->weight + P->convs[0].w_off, wpack, 64, P->cin0, P->kw, P->stem_K, st));
+  } else {
+    TBN_TRY(tbn_launch_nchw_to_s2d_pad(x_nchw, ws + P->x0_off, R, P->cin0, P->H, P->W, st));
+    TBN_TRY(tbn_launch_pack_stem_weight_s2d(prm->weight + P->convs[0].w_off, wpack, 64, P->cin0, st));
+  }
   if (!training)
     TBN_TRY(tbn_launch_bn_fold(prm->gamma, prm->beta, prm->running_mean, prm->running_var, prm->bias, prm->eps, scale,
                                shift, (int)P->chan_floats, st));
 
   auto fwd_params = [&](const Conv& c, ConvP& p) {
-    fill_fwd(P, c, ws, prm->weight, R, &p);
+    fill_fwd(P, c, training, ws, prm->weight, R, &p);
     if (training) {
       p.mode = CONV_EPI_STATS;
       p.nseg = 1;
@@ -889,18 +953,19 @@ int tbn_backbone_forward(const tbn_backbone_plan* P, int training, const float* 
   for (const Op& o : P->ops) {
     if (o.kind == OP_CONV) {
       const Conv& c = P->convs[o.idx];
-      if (c.pair_prev >= 0 && P->convs[c.pair_prev].pair_fwd) continue;   // ran with its sibling
-      if (c.pair_next >= 0 && c.pair_fwd) {
+      const Conv::FwdTune& T = c.ft[tr];
+      if (c.pair_prev >= 0 && P->convs[c.pair_prev].ft[tr].pair) continue;   // ran with its sibling
+      if (c.pair_next >= 0 && T.pair) {
         const Conv& c2 = P->convs[c.pair_next];
         ConvP pa, pb;
         fwd_params(c, pa);
         fwd_params(c2, pb);
         tbn_prof_label(("fwd " + c.parts[0].name + " | " + c2.parts[0].name).c_str());
-        TBN_TRY(tbn_launch_conv_pair(pa, pb, c.pf_variant, c.pf_mt, c.pf_nt, st));
+        TBN_TRY(tbn_launch_conv_pair(pa, pb, T.p_variant, T.p_mt, T.p_nt, st));
         continue;
       }
       ConvP p;
-      fill_fwd(P, c, ws, prm->weight, R, &p);
+      fill_fwd(P, c, training, ws, prm->weight, R, &p);
       tbn_prof_label(("fwd " + c.parts[c.nparts - 1].name).c_str());
       if (training) {
         // raw (bias-free) conv output of every part into the layer's y buffer + per-channel statistics partials
@@ -926,7 +991,7 @@ int tbn_backbone_forward(const tbn_backbone_plan* P, int training, const float* 
           if (q.pooled) p.raw_seg1 = i + 1;
         }
       }
-      TBN_TRY(tbn_launch_conv(p, c.stem, c.mt, c.nt, st));
+      TBN_TRY(tbn_launch_conv(p, c.stem, T.mt, T.nt, st));
     } else if (o.kind == OP_PREPOOL) {
       // pool_proj: 3x3 average of its conv output columns -> BN input (+ its batch statistics in training)
       const Conv& c = P->convs[o.idx];
@@ -966,7 +1031,7 @@ int tbn_backbone_forward(const tbn_backbone_plan* P, int training, const float* 
         const Pool& pl = P->pools[c0.fuse_pool];
         const Buf& ob = P->bufs[pl.outbuf];
         if (!diag_skip(2)) {
-          TBN_TRY(tbn_launch_bn_finalize(ws + P->partial_off + (size_t)c0.slot * P->partial_floats, cdiv(M, tile_rows(c0.halo, c0.mt)), M,
+          TBN_TRY(tbn_launch_bn_finalize(ws + P->partial_off + (size_t)c0.slot * P->partial_floats, cdiv(M, tile_rows(c0.ft[1].halo, c0.ft[1].mt)), M,
                                          q.cout, prm->gamma + q.c_off, prm->beta + q.c_off, prm->bias + q.c_off,
                                          prm->running_mean + q.c_off, prm->running_var + q.c_off, prm->momentum, prm->eps,
                                          mean + q.c_off, rstd + q.c_off, scale + q.c_off, shift + q.c_off, st));
@@ -1000,12 +1065,12 @@ int tbn_backbone_forward(const tbn_backbone_plan* P, int training, const float* 
           L.y_ld = c.cout;
           L.partial = ws + P->partial_off + (size_t)c.slot * P->partial_floats + q.col0;
           L.pld = c.cout;
-          int fmt = c.mt;      // M tile of the launch that wrote the statistics partials (a paired launch has its own)
-          if (c.pair_next >= 0 && c.pair_fwd) fmt = c.pf_mt;
-          if (c.pair_prev >= 0 && P->convs[c.pair_prev].pair_fwd) fmt = P->convs[c.pair_prev].pf_mt;
-          int frows = tile_rows(c.halo, c.mt);
-          if (fmt != c.mt || (c.pair_next >= 0 && c.pair_fwd) || (c.pair_prev >= 0 && P->convs[c.pair_prev].pair_fwd))
-            frows = 128 * fmt;
+          // M tile of the launch that wrote the statistics partials (a paired launch has its own); training mode here
+          const bool paired_first = c.pair_next >= 0 && c.ft[1].pair;
+          const bool paired_second = c.pair_prev >= 0 && P->convs[c.pair_prev].ft[1].pair;
+          int frows = tile_rows(c.ft[1].halo, c.ft[1].mt);
+          if (paired_first) frows = 128 * c.ft[1].p_mt;
+          if (paired_second) frows = 128 * P->convs[c.pair_prev].ft[1].p_mt;
           L.nparts = cdiv(M, frows);
         }
         L.gamma = prm->gamma + q.c_off;
@@ -1051,6 +1116,7 @@ int tbn_backbone_autotune(tbn_backbone_plan* P, int training, const tbn_backbone
   TBN_REQUIRE(workspace_bytes >= tbn_backbone_workspace_bytes(P, training), "autotune: workspace too small");
   float* ws = (float*)workspace;
   const int R = P->frames;
+  const int tr = training ? 1 : 0;
   float* scale = ws + P->stats_off + 2 * P->chan_floats;
   float* shift = scale + P->chan_floats;
   hipEvent_t e0, e1;
@@ -1082,7 +1148,7 @@ int tbn_backbone_autotune(tbn_backbone_plan* P, int training, const tbn_backbone
       if (pass == 1 && (!training || !c.need_dgrad)) continue;
       ConvP p;
       if (pass == 0) {
-        fill_fwd(P, c, ws, prm->weight, R, &p);
+        fill_fwd(P, c, training, ws, prm->weight, R, &p);
         p.nseg = 1;
         p.mode = training ? CONV_EPI_STATS : CONV_EPI_EVAL;
         p.scale = scale + c.c_off;
@@ -1148,11 +1214,12 @@ int tbn_backbone_autotune(tbn_backbone_plan* P, int training, const tbn_backbone
         }
       }
       if (pass == 0) {
-        c.mt = bm;
-        c.nt = bn;
-        c.stages = bs;
-        c.halo = bh;
-        c.t_fwd = best;
+        Conv::FwdTune& T = c.ft[tr];
+        T.mt = bm;
+        T.nt = bn;
+        T.stages = bs;
+        T.halo = bh;
+        T.t = best;
       } else {
         c.d_mt = bm;
         c.d_nt = bn;
@@ -1167,7 +1234,8 @@ int tbn_backbone_autotune(tbn_backbone_plan* P, int training, const tbn_backbone
   static const int use_pairs = getenv("TBN_USE_PAIRS") ? atoi(getenv("TBN_USE_PAIRS")) : 1;
   for (size_t ci = 0; ci < P->convs.size() && rc == TBN_OK; ++ci) {
     Conv& c = P->convs[ci];
-    c.pair_fwd = c.pair_dgrad = false;
+    c.ft[tr].pair = false;
+    if (training) c.pair_dgrad = false;      // an eval-mode tuning run leaves every data-gradient choice alone
     if (c.pair_next < 0 || !use_pairs) continue;
     Conv& c2 = P->convs[c.pair_next];
     for (int pass = 0; pass < 2 && rc == TBN_OK; ++pass) {
@@ -1177,7 +1245,7 @@ int tbn_backbone_autotune(tbn_backbone_plan* P, int training, const tbn_backbone
         for (int k = 0; k < 2; ++k) {
           Conv& m = k ? c2 : c;
           ConvP& p = k ? pb : pa;
-          fill_fwd(P, m, ws, prm->weight, R, &p);
+          fill_fwd(P, m, training, ws, prm->weight, R, &p);
           p.nseg = 1;
           p.mode = training ? CONV_EPI_STATS : CONV_EPI_EVAL;
           p.scale = scale + m.c_off;
@@ -1225,13 +1293,13 @@ int tbn_backbone_autotune(tbn_backbone_plan* P, int training, const tbn_backbone
           bv = cand[k].stages;
         }
       }
-      const float singles = pass == 0 ? c.t_fwd + c2.t_fwd : c.t_dgrad + c2.t_dgrad;
+      const float singles = pass == 0 ? c.ft[tr].t + c2.ft[tr].t : c.t_dgrad + c2.t_dgrad;
       const bool take = rc == TBN_OK && best < 0.97f * singles;
       if (pass == 0) {
-        c.pair_fwd = take;
-        c.pf_variant = bv;
-        c.pf_mt = bm;
-        c.pf_nt = bn;
+        c.ft[tr].pair = take;
+        c.ft[tr].p_variant = bv;
+        c.ft[tr].p_mt = bm;
+        c.ft[tr].p_nt = bn;
       } else {
         c.pair_dgrad = take;
         c.pd_variant = bv;
@@ -1396,7 +1464,10 @@ int tbn_backbone_backward(const tbn_backbone_plan* P, const float* dfeatures, co
       if (c.stem) {
         float* dwp = ws + P->dwpack_off;
         TBN_TRY(tbn_launch_wgrad(wp, 1, dwp, ws + P->wsplit_off, wst));
-        TBN_TRY(tbn_launch_unpack_stem_wgrad_s2d(dwp, g->dweight + c.w_off, 64, P->cin0, wst));
+        if (P->stem_mode == 1)
+          TBN_TRY(tbn_launch_unpack_stem_wgrad_rows(dwp, g->dweight + c.w_off, 64, P->cin0, P->kw, wst));
+        else
+          TBN_TRY(tbn_launch_unpack_stem_wgrad_s2d(dwp, g->dweight + c.w_off, 64, P->cin0, wst));
       } else {
         TBN_TRY(tbn_launch_wgrad(wp, 0, g->dweight + c.w_off, ws + P->wsplit_off, wst));
       }

@@ -386,6 +386,79 @@ __global__ void unpack_stem_wgrad_s2d_kernel(const float* __restrict__ dwp, floa
     dw[i] = dwp[(size_t)co * 64 * C + (a * 4 + b) * 4 * C + (py * 2 + px) * C + c];
   }
 }
+// ---------------------------------------------------------------- the 7x7 / stride 2 stem on a bordered NHWC image ("row runs")
+// For many input channels the space-to-depth form above multiplies 64*C K columns for 49*C taps x channels.  On a
+// zero-bordered NHWC image [N][HP][WP][C] (3 border pixels on the top / left) a filter ROW of output pixel (oy, ox) is
+// the 7*C CONTIGUOUS floats starting at pixel (2 oy + r, 2 ox): the K of a pixel = 7 such runs, each rounded up to a
+// multiple of 4 floats (RL; the extra floats are the next pixel's data and meet zero weights), packed back to back and
+// padded to a multiple of 32 with a run "7" that also meets zero weights: K = 512 instead of 640 for the 10-channel flow
+// stem (96 % useful columns instead of 77 %).  For 3 / 1 channels the 32-float K granularity gives 192 / 64 either way,
+// so RGB / audio keep the space-to-depth form (its 16-B aligned loads).  The image is HP = 2 (OH - 1) + 8 rows,
+// WP = 2 (OW - 1) + 8 columns: every run a launch reads lies inside it.
+template <int CT>   // CT > 0: compile-time channel count; 0: runtime
+__global__ __launch_bounds__(256) void nchw_to_nhwc_pad_kernel(const float* __restrict__ in, float* __restrict__ out, int N,
+                                                               int Crt, int H, int W, int HP, int WP) {
+  const int C = CT > 0 ? CT : Crt;
+  const size_t total = (size_t)N * HP * WP, hw = (size_t)H * W;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int X = (int)(i % WP);
+    const size_t t = i / WP;
+    const int Y = (int)(t % HP), n = (int)(t / HP);
+    const int y = Y - 3, x = X - 3;
+    const bool ok = (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+    const float* src = in + (size_t)n * C * hw + (ok ? (size_t)y * W + x : 0);
+    float* o = out + i * (size_t)C;
+    if (CT > 0 && CT % 2 == 0) {
+      float v[CT > 0 ? CT : 1];
+#pragma unroll
+      for (int c = 0; c < CT; ++c) v[c] = ok ? src[(size_t)c * hw] : 0.f;
+#pragma unroll
+      for (int c = 0; c < CT; c += 2) *reinterpret_cast<float2*>(o + c) = make_float2(v[c], v[c + 1]);   // pixel pitch 8-B aligned
+    } else {
+      for (int c = 0; c < C; ++c) o[c] = ok ? src[(size_t)c * hw] : 0.f;
+    }
+  }
+}
+
+int tbn_launch_nchw_to_nhwc_pad(const float* in, float* out, int N, int C, int H, int W, int HP, int WP, hipStream_t st) {
+  TBN_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0 && HP >= H + 3 && WP >= W + 3, "nchw_to_nhwc_pad: bad extents");
+  const dim3 grid(ew_grid((size_t)N * HP * WP));
+  if (C == 10)
+    hipLaunchKernelGGL(nchw_to_nhwc_pad_kernel<10>, grid, dim3(256), 0, st, in, out, N, C, H, W, HP, WP);
+  else
+    hipLaunchKernelGGL(nchw_to_nhwc_pad_kernel<0>, grid, dim3(256), 0, st, in, out, N, C, H, W, HP, WP);
+  TBN_CHECK_LAUNCH("nchw_to_nhwc_pad");
+  return TBN_OK;
+}
+
+// weights [Cout][7][7][C] -> [Cout][K]: k = r * RL + s * C + c holds w[r][s][c]; zero in the run padding and beyond 7 * RL
+__global__ void pack_stem_weight_rows_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int C, int RL, int K) {
+  const int total = Cout * K;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int co = i / K, k = i - co * K;
+    const int r = k / RL, q = k - r * RL;
+    wp[i] = (r < 7 && q < 7 * C) ? w[((size_t)(co * 7 + r) * 7) * C + q] : 0.f;
+  }
+}
+// packed weight gradient [Cout][7 * RL] -> [Cout][7][7][C]
+__global__ void unpack_stem_wgrad_rows_kernel(const float* __restrict__ dwp, float* __restrict__ dw, int Cout, int C, int RL) {
+  const int total = Cout * 49 * C;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int q = i % (7 * C), r = (i / (7 * C)) % 7, co = i / (49 * C);
+    dw[i] = dwp[(size_t)co * 7 * RL + r * RL + q];
+  }
+}
+int tbn_launch_pack_stem_weight_rows(const float* w, float* wp, int Cout, int C, int RL, int K, hipStream_t st) {
+  hipLaunchKernelGGL(pack_stem_weight_rows_kernel, dim3(cdiv(Cout * K, 256)), dim3(256), 0, st, w, wp, Cout, C, RL, K);
+  TBN_CHECK_LAUNCH("pack_stem_weight_rows");
+  return TBN_OK;
+}
+int tbn_launch_unpack_stem_wgrad_rows(const float* dwp, float* dw, int Cout, int C, int RL, hipStream_t st) {
+  hipLaunchKernelGGL(unpack_stem_wgrad_rows_kernel, dim3(cdiv(Cout * 49 * C, 256)), dim3(256), 0, st, dwp, dw, Cout, C, RL);
+  TBN_CHECK_LAUNCH("unpack_stem_wgrad_rows");
+  return TBN_OK;
+}
+
 int tbn_launch_pack_stem_weight_s2d(const float* w, float* wp, int Cout, int C, hipStream_t st) {
   hipLaunchKernelGGL(pack_stem_weight_s2d_kernel, dim3(cdiv(Cout * 64 * C, 256)), dim3(256), 0, st, w, wp, Cout, C);
   TBN_CHECK_LAUNCH("pack_stem_weight_s2d");

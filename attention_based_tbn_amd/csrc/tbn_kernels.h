@@ -87,8 +87,14 @@ struct WgradP {
   int rows_per_split;
   int mt, nt;             // host only: tile (32-column sub-tiles of Cout / Cin per workgroup), 0 = heuristic
   FastDiv div_ohw, div_ow, div_rl4;
+  // incremental row addressing of the kernel (filled by tbn_launch_wgrad): a lane's row advances 64 output pixels per step
+  unsigned mul_ow;        // ceil(2^32 / OW): oy = umulhi(pp, mul_ow) for the in-frame pixel index pp (pp * OW < 2^32); 0 when OW == 1
+  unsigned r64;           // 64 % (OH*OW)
+  unsigned frame_bytes;   // bytes of one input frame (H * W * pitch)
+  unsigned fb_lo, fb_hi;  // frame-base advance per step: (64 / (OH*OW)) frames, one more when pp wraps
+  unsigned row_step, col_step;   // ROWMODE: bytes per output row / column step in the padded image (stride folded in)
   double alg_flops;       // host only
-  unsigned dy_bytes, x_bytes;
+  unsigned dy_bytes, x_bytes;   // exact extents (last row ends at its last column): lanes beyond them read zeros
   int ablate;             // timing ablations, honoured by -DTBN_ABLATE=1 builds only (scripts/wgrad_ablate.py)
 };
 
@@ -203,3 +209,7 @@ int tbn_launch_spatial_mean_bwd(const float* dout, int dout_ld, float* din, int 
 int tbn_launch_nchw_to_s2d_pad(const float* in, float* out, int N, int C, int H, int W, hipStream_t st);
 int tbn_launch_pack_stem_weight_s2d(const float* w, float* wp, int Cout, int C, hipStream_t st);
 int tbn_launch_unpack_stem_wgrad_s2d(const float* dwp, float* dw, int Cout, int C, hipStream_t st);
+// row-run stem (bordered NHWC image, pool.hip): image [N][HP][WP][C], run length RL = 7*C rounded up to x4, K padded to x32
+int tbn_launch_nchw_to_nhwc_pad(const float* in, float* out, int N, int C, int H, int W, int HP, int WP, hipStream_t st);
+int tbn_launch_pack_stem_weight_rows(const float* w, float* wp, int Cout, int C, int RL, int K, hipStream_t st);
+int tbn_launch_unpack_stem_wgrad_rows(const float* dwp, float* dw, int Cout, int C, int RL, hipStream_t st);

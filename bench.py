@@ -83,11 +83,20 @@ def pmc_traffic(kernel):
         return None
     try:
         with open(files[-1]) as f:
-            k = json.load(f)["kernels"].get(kernel)
+            doc = json.load(f)
+        # a figure only counts for the kernels it was measured on: the file carries a hash of the kernel sources of its
+        # tree (scripts/pmc_traffic.py); any change to them since makes it stale -> reported as such, never silently
+        sys.path.insert(0, os.path.join(ROOT, "scripts"))
+        from pmc_traffic import source_hash
+        src = os.path.relpath(files[-1], ROOT)
+        if doc.get("source_sha16") != source_hash(ROOT):
+            return {"stale": True, "source": src,
+                    "why": "kernel sources changed since these counters were collected (source_sha16 mismatch)"}
+        k = doc["kernels"].get(kernel)
         return None if k is None else {"hbm_bytes_per_launch": k["hbm_bytes_per_launch"],
                                         "read": k["hbm_read_bytes_per_launch"], "write": k["hbm_write_bytes_per_launch"],
-                                        "source": os.path.relpath(files[-1], ROOT)}
-    except (OSError, ValueError, KeyError):
+                                        "source": src}
+    except (OSError, ValueError, KeyError, ImportError):
         return None
 
 
@@ -291,6 +300,30 @@ def main():
         step()
     L = lib()
     L.tbn_profile_reset()
+    probe = None
+    if world > 1:
+        # one-shot all-reduce probe on a tensor the size of a backbone's flat weight gradient (the largest collective of a
+        # step, ~41 MB), before the timed loop: makes the first real multi-GPU run self-explaining (link bandwidth vs
+        # exposed_allreduce_ms).  busbw = algbw * 2 (n - 1) / n (ring all-reduce convention).
+        nfl = max(int(b_.flat_weight.numel()) for b_ in bases)
+        buf = torch.zeros(nfl, device=device, dtype=torch.float32)
+        for _ in range(2):
+            dist.all_reduce(buf)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            dist.all_reduce(buf)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 5
+        t = torch.tensor([ms], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ms = float(t.item())
+        algbw = nfl * 4 / (ms * 1e-3) / 1e9
+        probe = {"bytes": nfl * 4, "ms": round(ms, 3), "algbw_GBps": round(algbw, 1),
+                 "busbw_GBps": round(algbw * 2 * (world - 1) / world, 1), "backend": dist.get_backend()}
+        del buf
     fence()
     if world > 1 and hasattr(model, "exposed_sync_ms"):
         model.exposed_sync_ms()     # drop the warm-up records
@@ -312,10 +345,13 @@ def main():
                 b_.use_aux_stream = a_
     fence()
     dt = time.perf_counter() - t0
+    rank_ms = None
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        every = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(every, t)
+        rank_ms = [1e3 * float(x.item()) / args.steps for x in every]      # each rank's own clock around the same K steps
+        dt = max(float(x.item()) for x in every)                            # the job's time = the slowest rank
     assert os.environ.get("TBN_DIAG_SKIP") or torch.isfinite(loss).item(), "loss is not finite"
     if args.trace_streams and rank == 0:
         from attention_based_tbn_amd import _lib
@@ -353,12 +389,20 @@ def main():
             ach = top["flops"] / (top["ms"] * 1e-3) / 1e12
             tot_ms, tot_fl = sum(e["ms"] for e in prof), sum(e["flops"] for e in prof)
             tr = pmc_traffic(top["kernel"])
+            tr_detail = tr
+            if tr and tr.get("stale"):
+                tr = None                      # stale counters: traffic is null, the detail says why
             alg_b = top["alg_bytes"] / max(1, top["launches"])
+            fam = {}
+            for e in prof:                     # launches per kernel family in the profiled step(s): which variants the
+                f_ = e["kernel"].split("<")[0]  # per-layer autotuner actually put on this shape
+                fam[f_] = fam.get(f_, 0) + e["launches"]
             roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": (tr or {}).get("hbm_bytes_per_launch"),
                         "alg_bytes_per_launch": round(alg_b),
                         "traffic_ratio": round(tr["hbm_bytes_per_launch"] / alg_b, 3) if tr and alg_b > 0 else None,
-                        "traffic_detail": tr,
+                        "traffic_detail": tr_detail,
+                        "kernel_families": fam,
                         "kernel": top["kernel"], "launches": top["launches"],
                         "avg_launch_us": round(1e3 * top["ms"] / top["launches"], 2),
                         "alg_gflop_per_launch": round(top["flops"] / top["launches"] / 1e9, 4),
@@ -382,6 +426,10 @@ def main():
                        **({"audio_input": "waveform (30695 samples), STFT kernel inside the timed step"} if args.stft_inputs else {})},
             "roofline": roofline,
         }
+        if world > 1:
+            line["multi_gpu"] = {"dist_world_size": dist.get_world_size(), "cuda_device_count": torch.cuda.device_count(),
+                                 "ms_per_step_rank_min": round(min(rank_ms), 3), "ms_per_step_rank_max": round(max(rank_ms), 3),
+                                 "allreduce_probe": probe}
         if exposed_ms is not None:
             # mean GPU time per step between the end of the last backbone's backward (entry of the gradient-sync
             # callback on the compute stream) and the return of finish_gradient_sync, max over ranks

@@ -89,9 +89,18 @@ size_t tbn_backbone_workspace_bytes(const tbn_backbone_plan* plan, int training)
 int tbn_backbone_out_shape(const tbn_backbone_plan* plan, int* h, int* w, int* c);
 /* test / debug aid: location of one conv's tensors inside the workspace (floats). kind 0: z =
  * relu(bn(conv)) destination slice, 1: BN input y (overwritten by dy in backward), 2: gradient
- * wrt z (offset -1 when it is the caller-supplied dfeatures), 3: the conv's whole input buffer. */
+ * wrt z (offset -1 when it is the caller-supplied dfeatures), 3: the conv's whole input buffer, 4: its training-mode
+ * BatchNorm coefficients as 4 rows x cout (batch mean | 1/std | scale | shift).  Kind 0 of a conv whose max pool runs
+ * inside its BN apply (conv1_7x7_s2, conv2_3x3 in training) fails with TBN_ERR_UNSUPPORTED: that z is never written --
+ * it is relu(fma(y, scale, shift)) of kinds 1 and 4. */
 int tbn_backbone_tensor_info(const tbn_backbone_plan* plan, const char* conv_name, int kind, long* offset, int* rows,
                              int* cols, int* ld);
+/* test / diagnostics aid: the launch choices the plan holds for one conv (after tbn_backbone_autotune: the tuned ones,
+ * before: the size heuristics).  Forward choices are kept PER MODE (`training` selects which); the data-gradient ones
+ * only exist for training.  out[0..7]  = forward: kernel variant (0 register-staged implicit GEMM, 1 LDS-halo, 2 LDS-DMA,
+ * 3 split-K tile), M tile, N tile, LDS stages, issued as a sibling pair (0 / 1; on the pair's first member), pair variant,
+ * pair M tile, pair N tile; out[8..15] = the same for the data gradient (zeros when the layer has none / training == 0). */
+int tbn_backbone_launch_info(const tbn_backbone_plan* plan, const char* conv_name, int training, int* out16);
 /* x_nchw: (frames, in_channels, H, W) contiguous, as the reference passes it (model.py:213).
  * training=1: batch-statistics BN, keeps activations in the workspace for backward, updates
  * running stats; training=0: running-stat BN folded into the conv epilogue.
@@ -136,6 +145,49 @@ int tbn_conv2d_fwd_tile(const float* in, int in_ld, const float* weight, const f
 int tbn_conv2d_dgrad(const float* dout, int dout_ld, const float* weight, float* din, int din_ld, int n, int h, int w,
                      int cin, int cout, int ksize, int stride, int pad, int accumulate, float* workspace,
                      void* stream);
+/* ---- one convolution launch in full detail (test / tuning aid) --------------------------------
+ * Reaches every kernel variant, tile, epilogue and the fused BN-backward reduce that the backbone engine's autotuner
+ * can put on a layer -- including the forms the plain entry points above never select by themselves: explicit tiles of
+ * the parity-phase launch of a strided data gradient, data-gradient / eval epilogues of the LDS-halo / LDS-DMA /
+ * split-K tile kernels, the reduce epilogue, and two sibling convolutions in ONE launch.
+ * replaces: the same nn.Conv2d forward / backward of bn_inception_audio.py:24-401 as tbn_conv2d_*. */
+typedef struct {
+  const float* y;         /* BN input of the producer layer at its column 0 (pitch y_ld), output pixel order */
+  int y_ld;
+  int col_begin;          /* first output column of this layer (multiple of 32, ascending, disjoint) */
+  int channels;
+  int stat_offset;        /* this layer's channel 0 inside the red_stats arrays */
+  float* partial;         /* [tbn_conv_partial_rows()][2][channels]: per M tile  sum g | sum g * xhat */
+} tbn_conv_red;
+typedef struct {
+  const float* in;        /* forward: input (n,h,w,cin); data gradient: dout (n,oh,ow,cout) */
+  int in_ld;
+  const float* weight;    /* [cout][k][k][cin] */
+  const float* bias;      /* epilogue 0 of a forward launch; may be NULL */
+  float* out;             /* forward: (n,oh,ow,cout); data gradient: din (n,h,w,cin) */
+  int out_ld;
+  int n, h, w, cin, cout, ksize, stride, pad;   /* geometry of the FORWARD convolution */
+  int dgrad;              /* 0: forward, 1: data gradient of that convolution (workspace: cout*k*k*cin floats) */
+  int epilogue;           /* forward: 0 / 1 / 2 as tbn_conv2d_fwd; data gradient: 0 */
+  int flags;              /* 1 accumulate, 2 ReLU; kernel variant 4 LDS-halo, 8 LDS-DMA, 16 split-K tile (0 generic) */
+  int stages;             /* generic kernel: LDS stages 1 / 2 (0 = default) */
+  const float* scale;     /* epilogue 2 */
+  const float* shift;
+  float* stat_partial;    /* epilogue 1: [tbn_conv_partial_rows()][2][cout] */
+  int nred;               /* data gradient: fused BN-backward reduce over nred producer layers (0 = off) */
+  tbn_conv_red red[4];
+  const float* red_stats; /* mean | rstd | scale | shift, each red_stats_stride floats */
+  int red_stats_stride;
+} tbn_conv_desc;
+/* rows of stat_partial / red[i].partial that a launch with M tile `mt` writes (pair = 1: issued by tbn_conv_launch_pair) */
+int tbn_conv_partial_rows(const tbn_conv_desc* d, int mt, int pair);
+int tbn_conv_launch(const tbn_conv_desc* d, int mt, int nt, float* workspace, void* stream);
+/* two independent unit-stride convolutions with the same epilogue in ONE launch (the 3x3 | double_3x3_1 siblings of an
+ * inception block): variant 0 LDS-halo (both 3x3 / stride 1 / pad 1), 1 / 2 generic kernel with 1 / 2 LDS stages;
+ * mt, nt in {1,2} */
+int tbn_conv_launch_pair(const tbn_conv_desc* a, const tbn_conv_desc* b, int variant, int mt, int nt,
+                         float* workspace_a, float* workspace_b, void* stream);
+
 /* weight gradient: dweight [cout][k][k][cin].  workspace: tbn_conv2d_wgrad_workspace_floats(). */
 size_t tbn_conv2d_wgrad_workspace_floats(int n, int h, int w, int cin, int cout, int ksize, int stride, int pad);
 int tbn_conv2d_wgrad(const float* dout, int dout_ld, const float* in, int in_ld, float* dweight, int n, int h, int w,
@@ -162,6 +214,20 @@ int tbn_bn_relu_train_fwd(const float* y, int p, int c, const float* gamma, cons
 int tbn_bn_relu_train_bwd(const float* dz, int dz_ld, const float* y, int p, int c, const float* save_mean,
                           const float* save_rstd, const float* scale, const float* shift, float* dy, float* dgamma,
                           float* dbeta, float* workspace, void* stream);
+
+/* training-mode BatchNorm2d + ReLU + MaxPool2d(3, stride, pad, ceil_mode) in one pass over y: z = relu(bn(y)) is pooled in
+ * registers and never written (what the backbone does for conv1_7x7_s2 -> pool1 and conv2_3x3 -> pool2, the two largest
+ * tensors of the network); the backward gathers dz from (dpooled, argmax) on the fly.  y: (n,h,w,c) NHWC, pooled:
+ * (n,oh,ow,c) with pitch pooled_ld, argmax: n*oh*ow*c bytes.  Workspace: tbn_bn_workspace_floats(n*h*w, c).
+ * replaces: BatchNorm2d.train() + ReLU + MaxPool2d of bn_inception_audio.py:21-23,28-34. */
+int tbn_bn_relu_maxpool_train_fwd(const float* y, int n, int h, int w, int c, const float* gamma, const float* beta,
+                                  float* running_mean, float* running_var, float momentum, float eps, float* save_mean,
+                                  float* save_rstd, float* scale, float* shift, float* pooled, int pooled_ld,
+                                  uint8_t* argmax, int oh, int ow, int stride, int pad, float* workspace, void* stream);
+int tbn_bn_relu_maxpool_train_bwd(const float* dpooled, int dpooled_ld, const uint8_t* argmax, const float* y, int n, int h,
+                                  int w, int c, int oh, int ow, int stride, int pad, const float* save_mean,
+                                  const float* save_rstd, const float* scale, const float* shift, float* dy,
+                                  float* dgamma, float* dbeta, float* workspace, void* stream);
 
 /* pooling (bn_inception_audio.py:21-23,86-88,155-157,394-396; ceil_mode handled by oh/ow) */
 int tbn_maxpool3_fwd(const float* in, int in_ld, float* out, int out_ld, uint8_t* argmax, int n, int h, int w, int c,

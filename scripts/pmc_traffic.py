@@ -11,10 +11,25 @@ dispatch (priming step with the per-layer tile autotune + warm-up steps) is drop
          gpurun_out/pmc_write/write_counter_collection.csv profiles/r02_pmc_traffic.json [SKIP=3] [note]
 """
 import csv
+import hashlib
 import json
+import os
 import re
 import sys
 from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# the kernel sources a traffic figure belongs to: bench.py refuses the file when any of them changed since
+KERNEL_SOURCES = ["attention_based_tbn_amd/csrc/conv_igemm.hip", "attention_based_tbn_amd/csrc/engine.hip",
+                  "attention_based_tbn_amd/csrc/tbn_kernels.h", "attention_based_tbn_amd/build.py"]
+
+
+def source_hash(root=ROOT):
+    h = hashlib.sha256()
+    for rel in KERNEL_SOURCES:
+        with open(os.path.join(root, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
 
 
 def short(name):
@@ -63,6 +78,7 @@ def main():
                    "the launches of that kernel name in the TIMED steps of bench.py --steps 3 --warmup 2 --profile-every 1 "
                    f"(B=32; the first {skip} steps -- priming with autotune + warm-up -- are filtered out)"
                    + (" | " + sys.argv[5] if len(sys.argv) > 5 else ""),
+           "source_sha16": source_hash(),   # sha256 over KERNEL_SOURCES of the tree the counters were collected from
            "total_hbm_bytes_all_launches": tot, "kernels": out}
     with open(sys.argv[3], "w") as f:
         json.dump(res, f, indent=1)

@@ -41,7 +41,13 @@ from attention_based_tbn_amd.config import load_config  # noqa: E402
 
 
 def install_stubs():
+    # idempotent: reference modules imported after the first call hold references to THESE stub modules; a second call
+    # (make_golden_trainstep.py runs several generators in one process) must not replace them, or attributes set later
+    # (cv2.resize) would land on modules the reference code never sees
+    if getattr(sys.modules.get("cv2"), "_tbn_stub", False):
+        return
     cv2 = types.ModuleType("cv2")
+    cv2._tbn_stub = True
     cv2.INTER_LINEAR = 1
     cv2.getGaussianKernel = lambda n, sigma: gaussian_kernel(n, sigma)
     sys.modules["cv2"] = cv2

@@ -173,32 +173,39 @@ assert float(model.module.stat[0]) == 0.0 and int(model.module.count[1]) == 0   
 g = torch.Generator().manual_seed(7)
 X = torch.randn(8, 8, generator=g); Y = torch.randn(8, 2, generator=g)
 xs, ys = X[rank * 4:(rank + 1) * 4], Y[rank * 4:(rank + 1) * 4]   # clips sharded by rank, no data-path collective
-drops = {"avg": (False, False), "drop1": (False, True), "dropall": (True, True)}[case]
-model.module.drop = drops[rank]
-loss, bs = model.get_loss(nn.MSELoss(), ys, model(xs), epoch=3)
-loss["total"].backward()
-outs = []
-for r in range(2):                                  # full-batch reference on every rank, same per-shard decisions
-    ref.drop = drops[r]
-    outs.append(ref(X[r * 4:(r + 1) * 4]))
-nn.MSELoss()(torch.cat(outs), Y).backward()
-for (n, p), (_, q) in zip(model.module.named_parameters(), ref.named_parameters()):
-    if q.grad is None:                              # nobody produced it: the optimiser must see None
-        assert case == "dropall" and n.startswith("c.") and p.grad is None, n
-    else:
-        assert p.grad is not None and torch.allclose(p.grad, q.grad, atol=1e-6), n
-assert model._pending == [] and model._fired == set() and bs == 4
+# one entry per consecutive step: (rank 0 drops, rank 1 drops).  "flip": the decision changes from step to step --
+# dropped on one rank, on both, on the other, on none -- so presence flags, _pending and _fired must reset every step
+steps = {"avg": [(False, False)], "drop1": [(False, True)], "dropall": [(True, True)],
+         "flip": [(False, True), (True, True), (True, False), (False, False), (True, True)]}[case]
+for it, drops in enumerate(steps):
+    model.zero_grad(set_to_none=True); ref.zero_grad(set_to_none=True)
+    model.module.drop = drops[rank]
+    loss, bs = model.get_loss(nn.MSELoss(), ys, model(xs), epoch=3)
+    loss["total"].backward()
+    outs = []
+    for r in range(2):                              # full-batch reference on every rank, same per-shard decisions
+        ref.drop = drops[r]
+        outs.append(ref(X[r * 4:(r + 1) * 4]))
+    nn.MSELoss()(torch.cat(outs), Y).backward()
+    for (n, p), (_, q) in zip(model.module.named_parameters(), ref.named_parameters()):
+        if q.grad is None:                          # nobody produced it: the optimiser must see None
+            assert drops == (True, True) and n.startswith("c.") and p.grad is None, (it, n)
+        else:
+            assert p.grad is not None and torch.allclose(p.grad, q.grad, atol=1e-6), (it, n)
+    assert model._pending == [] and model._fired == set() and not model._callback_queued and bs == 4
 sd = model.state_dict(); assert all(k.startswith("module.") for k in sd)
 print("DP_OK", rank)
 '''
 
 
 @pytest.mark.parametrize("overlap,case", [(True, "avg"), (False, "avg"), (True, "drop1"), (False, "drop1"),
-                                          (True, "dropall")])
+                                          (True, "dropall"), (True, "flip"), (False, "flip")])
 def test_dataparallel_gradient_average_gloo_world2(tmp_path, overlap, case):
     """2 gloo ranks: gradients equal the full-batch ones; with an optional branch (the audio-dropout rule, reference
     model.py:215-222, drawn per replica) dropped on ONE rank the collective schedule still matches and the result is
-    the full-batch gradient; dropped on every rank its gradients come back as None"""
+    the full-batch gradient; dropped on every rank its gradients come back as None; "flip" runs five CONSECUTIVE steps
+    whose drop decision changes every step (one rank, both, the other, none, both): the wrapper's per-step state
+    (presence flags, pending collectives, fired hooks, the queued callback) must reset between them"""
     script = tmp_path / "dp_worker.py"
     script.write_text(_DP_WORKER)
     with socket.socket() as s:

@@ -355,9 +355,10 @@ def test_backbone_all_layer_grads_forced_decisions(cin_hw, monkeypatch):
     product's (z > 0) masks, its max pools route through the entry the product selected (both read back from the
     engine workspace), and everything else -- convolutions, batch statistics, the whole backward -- is the oracle's own
     fp64 arithmetic.  What remains is the arithmetic error of the 69 weight-gradient / data-gradient / BN-backward
-    steps: merged 1x1 groups, reduce-in-epilogue, parity-phase strided gradients, LDS-halo 3x3 kernels included.
-    (Pool fusion of the stem is switched off for this plan so that every z exists in memory; the fused stem kernels
-    keep their own parity tests.)"""
+    steps: merged 1x1 groups, reduce-in-epilogue, parity-phase strided gradients, LDS-halo 3x3 kernels AND the shipped
+    fused stem kernels (conv1 / conv2_3x3: BN apply + ReLU + max pool in one pass, BN backward on 2x2 blocks) included:
+    their z is never written, so the test rebuilds it bit-exactly as relu(fma(y, scale, shift)) from the engine's y and
+    batch-statistics coefficients (tbn_backbone_tensor_info kinds 1 and 4) and finds the pool route from the pooled values."""
     import copy
     import ctypes as C
     from oracle.bninception import BNInception as OBN
@@ -366,7 +367,6 @@ def test_backbone_all_layer_grads_forced_decisions(cin_hw, monkeypatch):
     from attention_based_tbn_amd.core.models.bn_inception import BNInception
     cin, H, W = cin_hw
     N = 2
-    monkeypatch.setenv("TBN_NO_FUSE_POOL", "1")
     ora = OBN(1000, cin)
     sd = fill_state_dict(ora.state_dict(), 42)
     ora.load_state_dict(sd)
@@ -389,12 +389,27 @@ def test_backbone_all_layer_grads_forced_decisions(cin_hw, monkeypatch):
         h, w = like_hw
         return rows.view(N, h, w, -1).permute(0, 3, 1, 2).contiguous()
 
+    from attention_based_tbn_amd._lib import TbnHipError
+    fused = []
+
+    def z_of(name):
+        """z = relu(bn(conv)) as the product formed it.  A conv whose max pool runs inside its BN apply never writes z:
+        the engine computes fmaxf(fmaf(y, scale, shift), 0) per element in registers -- rebuilt here from its y and its
+        coefficients (the products and sums of fp32 values are exact in fp64; one rounding to fp32, like the fma)"""
+        try:
+            return tensor(name, 0)
+        except TbnHipError:
+            fused.append(name)
+            yv, co = tensor(name, 1).double(), tensor(name, 4).double()
+            return torch.clamp_min(yv * co[2] + co[3], 0.0).float()
+
     # the product's decisions -> the fp64 oracle
     names = [n for n, m in o64.named_children() if isinstance(m, torch.nn.Conv2d)]
     relus = [n for n, m in o64.named_children() if isinstance(m, torch.nn.ReLU)]
     assert len(names) == len(relus) == 69
     for cname, rname in zip(names, relus):
-        setattr(o64, rname, _ForcedReLU(tensor(cname, 0) > 0))
+        setattr(o64, rname, _ForcedReLU(z_of(cname) > 0))
+    assert fused == ["conv1_7x7_s2", "conv2_3x3"], fused      # the shipped plan fuses exactly the two stem pools
     shapes = {}
     hooks = [m.register_forward_pre_hook(lambda mod, inp, k=k: shapes.__setitem__(k, inp[0].shape[2:]))
              for k, m in ora.named_children() if isinstance(m, torch.nn.MaxPool2d)]
@@ -405,8 +420,8 @@ def test_backbone_all_layer_grads_forced_decisions(cin_hw, monkeypatch):
     for h in hooks:
         h.remove()
     pools = {
-        "pool1_3x3_s2": (tensor("conv1_7x7_s2", 0), tensor("conv2_3x3_reduce", 3)),
-        "pool2_3x3_s2": (tensor("conv2_3x3", 0), tensor("inception_3a_1x1", 3)),
+        "pool1_3x3_s2": (z_of("conv1_7x7_s2"), tensor("conv2_3x3_reduce", 3)),
+        "pool2_3x3_s2": (z_of("conv2_3x3"), tensor("inception_3a_1x1", 3)),
         "inception_3c_pool": (tensor("inception_3c_3x3_reduce", 3), tensor("inception_4a_1x1", 3)[:, 256:576]),
         "inception_4e_pool": (tensor("inception_4e_3x3_reduce", 3), tensor("inception_5a_1x1", 3)[:, 448:1056]),
         "inception_5b_pool": (tensor("inception_5b_1x1", 3), tensor("inception_5b_pool_proj", 3)),
@@ -433,6 +448,149 @@ def test_backbone_all_layer_grads_forced_decisions(cin_hw, monkeypatch):
                 worst = (e, key)
             assert e < 5e-4, (key, e)         # the north star asks 1e-3; observed worst over all five cases: 1.05e-4
     print(f"forced-decision gradient case {cin_hw}: worst relative L2 error {worst[0]:.2e} at {worst[1]}")
+
+
+def test_config4_full_batch_train_step_vs_oracle():
+    """Parity AT THE BENCHMARKED OPERATING POINT (round-2 verdict): BASELINE config 4 at B = 32 clips x 3 segments, i.e.
+    R = 96 frames per backbone -- the plans, per-layer autotune choices and split-K plans `bench.py` times (LDS-DMA,
+    sibling pairs, split-K tiles, 160-wide weight-gradient tiles only win at this size) -- one training step (reference
+    loop body core/tools/train.py:76-81) against the CPU oracle with the same weights and full-size synthetic inputs:
+    logits, losses and every BN running statistic within 1e-3; the gradient norm and each backbone's conv weight
+    gradients against the oracle's own fp32 step (relative L2 < 2e-2, cosine > 0.999: at 96 frames per BatchNorm the
+    last-bit ReLU / max-pool decision flips that dominate the small-batch gradient tests average out).  The oracle step
+    takes about a minute on the GPU box's host cores."""
+    import ctypes as C
+    import time
+    from attention_based_tbn_amd._lib import lib
+    cfg, modality, meta, _, _, _ = load_case("train_cfg4_all_noattn")
+    assert modality == ["RGB", "Flow", "Audio"]
+    B, n = 32, 3
+    g = torch.Generator().manual_seed(0)
+    mean = torch.tensor([0.408, 0.459, 0.502]).view(1, 1, 3, 1, 1)
+    inp = {"RGB": torch.rand(B, n, 3, 224, 224, generator=g) - mean,
+           "Flow": torch.rand(B, n, 10, 224, 224, generator=g) - 0.502,
+           "Audio": (torch.randn(B, n, 1, 256, 256, generator=g) * 3 - 6).clamp_(-13.8155, 8.0)}
+    target = {"class": {"verb": torch.randint(0, 125, (B,), generator=g), "noun": torch.randint(0, 352, (B,), generator=g)}}
+    model, crit = build_product(cfg, modality, meta)
+    model.train()
+    L = lib()
+    L.tbn_profile_reset()
+    model.zero_grad()
+    dinp = to_dev(inp)
+    tgt = {"class": to_dev(target["class"])}
+    out = model(dinp)                       # first use of the shape: per-layer autotune, as in bench.py's priming step
+    loss, _ = model.get_loss(crit, tgt, out, epoch=0)
+    loss["total"].backward()
+    # second step with the launches bracketed: which kernel families the tuned plan runs (weights unchanged: same step)
+    sd_post = {k: v.clone() for k, v in model.state_dict().items()}
+    model.load_state_dict(fill_sd(model, meta))
+    model.zero_grad()
+    L.tbn_profile_enable(1)
+    out = model(dinp)
+    loss, _ = model.get_loss(crit, tgt, out, epoch=0)
+    loss["total"].backward()
+    torch.cuda.synchronize()
+    L.tbn_profile_enable(0)
+    fam = {}
+    name = C.create_string_buffer(160)
+    for i in range(L.tbn_profile_num_entries()):
+        cnt, ms, fl = C.c_long(), C.c_double(), C.c_double()
+        L.tbn_profile_entry(i, name, 160, C.byref(cnt), C.byref(ms), C.byref(fl))
+        f_ = name.value.decode().split("<")[0]
+        fam[f_] = fam.get(f_, 0) + cnt.value
+    L.tbn_profile_reset()
+    print("kernel families at R = 96:", fam)
+    for need in ("conv_igemm_kernel", "conv_halo_kernel", "conv_igemm_phases_kernel", "conv_sk4_kernel", "conv_wgrad_kernel"):
+        assert fam.get(need, 0) > 0, (need, fam)
+    assert fam.get("conv_pair_igemm_kernel", 0) + fam.get("conv_pair_halo_kernel", 0) > 0, fam
+    # the two product steps started from the same weights: deterministic kernels -> identical statistics updates
+    for k, v in model.state_dict().items():
+        assert torch.equal(v, sd_post[k]), k
+
+    t0 = time.time()
+    oracle, ocrit = build_oracle(cfg, modality, meta)
+    oracle.train()
+    oout = oracle(inp)
+    oloss, _ = oracle.get_loss(ocrit, target, oout, epoch=0)
+    oloss["total"].backward()
+    print("oracle step at B = 32: %.1f s on %d threads" % (time.time() - t0, torch.get_num_threads()))
+    for k in ("verb", "noun"):
+        assert rel_err(out[k].detach().cpu(), oout[k].detach()) < 1e-3, (k, rel_err(out[k].detach().cpu(), oout[k].detach()))
+    for k, v in oloss.items():
+        want = float(torch.as_tensor(v).detach())
+        assert abs(float(torch.as_tensor(loss[k]).detach()) - want) < 1e-3 * max(1.0, abs(want)), k
+    osd = oracle.state_dict()
+    checked = 0
+    for k, v in model.state_dict().items():
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            assert rel_err(v.double().cpu(), osd[k].double()) < 1e-3, k
+            checked += 1
+    assert checked == 2 * 69 * 3
+    grads = reference_named_grads(model)
+    ograds = {k: p.grad for k, p in oracle.named_parameters() if p.grad is not None}
+    worst = (0.0, None)
+    for m in modality:
+        got = torch.cat([grads[k].reshape(-1).cpu() for k in sorted(grads) if k.startswith(f"Base_{m}.") and k.endswith(".weight")
+                         and "_bn." not in k])
+        want = torch.cat([ograds[k].reshape(-1) for k in sorted(grads) if k.startswith(f"Base_{m}.") and k.endswith(".weight")
+                          and "_bn." not in k])
+        e = l2_err(got, want)
+        worst = max(worst, (e, m))
+        assert e < 2e-2 and cosine(got, want) > 0.999, (m, e)
+    gn = torch.sqrt(sum((v.double() ** 2).sum() for v in grads.values()))
+    ogn = torch.sqrt(sum((v.double() ** 2).sum() for k, v in ograds.items() if k in grads))
+    assert abs(float(gn) - float(ogn)) < 2e-2 * float(ogn), (float(gn), float(ogn))
+    print("R = 96 parity: worst backbone weight-gradient relative L2 %.2e (%s), grad norm %.5f vs %.5f" %
+          (worst[0], worst[1], float(gn), float(ogn)))
+
+
+def fill_sd(model, meta):
+    from oracle.fill import fill_state_dict
+    return fill_state_dict(model.state_dict(), meta["fill_seed"])
+
+
+def test_autotune_choices_are_kept_per_mode():
+    """a validation pass at the training shape tunes the EVAL epilogue of the same plan: it must not overwrite the
+    launch choices (tile, kernel variant, stages, sibling pairing; forward and data gradient) training was tuned to
+    (round-2 advisor finding: shared plan fields).  Checked through tbn_backbone_launch_info, and by the training step
+    reproducing its own output bit for bit afterwards (every kernel is deterministic for a given choice)."""
+    import ctypes as C
+    from attention_based_tbn_amd._lib import call
+    from attention_based_tbn_amd.core.models.bn_inception import BNInception
+    torch.manual_seed(3)
+    net = BNInception(1000, 3).to(DEV).train()
+    N, H, W = 6, 96, 96
+    x = torch.randn(N, 3, H, W, device=DEV)
+
+    def train_step():
+        net.zero_grad()
+        rm = net.running_mean.clone()
+        out = net(x)
+        out.square().mean().backward()
+        net.running_mean.copy_(rm)            # same statistics state for the repeat
+        return out.detach().clone(), net.flat_weight.grad.clone()
+
+    def choices(training):
+        plan = net._plans[(N, H, W)]
+        out = {}
+        for name in net._layers:
+            buf = (C.c_int * 16)()
+            call("tbn_backbone_launch_info", plan.handle, name.encode(), training, buf)
+            out[name] = tuple(buf)
+        return out
+
+    y0, g0 = train_step()
+    before = choices(1)
+    assert any(v[8:] != (0,) * 8 for v in before.values())          # data-gradient choices exist in training mode
+    net.eval()
+    with torch.no_grad():
+        net(x)                                                       # tunes the eval epilogue of the same plan
+    ev = choices(0)
+    assert all(v[8:] == (0,) * 8 for v in ev.values())              # no data gradient in eval mode
+    net.train()
+    assert choices(1) == before
+    y1, g1 = train_step()
+    assert torch.equal(y0, y1) and torch.equal(g0, g1)
 
 
 def test_full_size_properties_config4_shapes():
