@@ -269,7 +269,8 @@ bool build_graph(tbn_backbone_plan* P) {
     // row runs on the bordered NHWC image when that multiplies fewer K columns (flow: 512 instead of 640; RGB / audio:
     // the same 192 / 64 -> they keep the space-to-depth form and its 16-B aligned loads)
     const int rl = (7 * cin0 + 3) / 4 * 4, krows = (7 * rl + 31) / 32 * 32;
-    if (krows < P->stem_K) {
+    static const int use_rows = getenv("TBN_STEM_ROWS") ? atoi(getenv("TBN_STEM_ROWS")) : 1;   // A/B runs: 0 = always s2d
+    if (krows < P->stem_K && use_rows) {
       const int oh = (P->H + 6 - 7) / 2 + 1, ow = (P->W + 6 - 7) / 2 + 1;
       P->stem_mode = 1;
       P->cp = cin0;

@@ -6,16 +6,21 @@
 // bins are a dense 256 x 240 real DFT: X[k] = sum_j hann[j] * y[120 t - 120 + j] * e^{-2 pi i (j+135) k / 511}.
 // That is a [bins x taps] x [taps x frames] contraction -> fp32 MFMA (32x32x2), 2 * 2 * 256 * 240 FLOP per frame.
 //
-// Workgroup = 128 bins x 64 frames of one segment (4 waves x 32 bins; re and im of 2 frame tiles = 4 accumulators).
+// Workgroup = ALL 256 bins x 64 frames of one segment: 8 waves x 32 bins; re and im of 2 frame tiles = 4 accumulators
+// per wave (round 2: two workgroups of 4 waves each re-staged the same frames for half the bins).
 //   * frames (B operand): hop = 120, 240 taps -> consecutive frames overlap by half.  The RAW samples of the 64
-//     frames (65 hop rows of 120) are staged once in LDS with rows padded to 124 floats: frame f, tap j lives at
-//     (f + j / 120) * 124 + j % 120, no im2col copy, and a lane's four consecutive taps are one conflict-free
-//     ds_read_b128 (lane stride 496 B -> 16 distinct 16-B slots per 16-lane group);
+//     frames (65 hop rows of 120) are staged ONCE per workgroup in LDS with rows padded to 124 floats: frame f, tap j
+//     lives at (f + j / 120) * 124 + j % 120, no im2col copy, and a lane's four consecutive taps are one conflict-free
+//     ds_read_b128 (lane stride 496 B -> 16 distinct 16-B slots per 16-lane group).  The 65 rows are one contiguous
+//     span of the waveform: staged with 16-B buffer loads (1950 of them per workgroup, 4 per thread) whose hardware
+//     range check supplies the zero padding in front of the first and behind the last sample;
 //   * twiddles (A operand): the window is folded into the table, stored [cos | -sin][tap / 8][bin][tap % 8]: the
 //     fragment of 8 taps x 32 bins is ONE fully coalesced 1-KB load per wave (the table is 480 KB, shared by every
 //     workgroup: L2 resident), prefetched one 8-tap group ahead; each load feeds 8 MFMAs;
 //   * k is permuted identically for A and B (lane half h holds taps 4h..4h+3 of the group) so one 16-B fragment
-//     feeds four MFMAs; accumulators put frames on lanes -> the (256, W) freq-major rows are written 128 B contiguous.
+//     feeds four MFMAs; accumulators put frames on lanes -> the (256, W) freq-major rows are written 128 B contiguous;
+//   * log(|X|^2 + eps) with the hardware logarithm (v_log_f32, 1 ulp): 3 VALU instructions per output instead of the
+//     ~20 of logf's software path (32 outputs per lane: the epilogue was 8 % of the kernel).
 #include <cmath>
 #include <cstring>
 
@@ -28,20 +33,46 @@
 #define STFT_FR 64     // frames per workgroup
 #define STFT_PITCH 124 // LDS floats per hop row of 120 samples
 
-__global__ __launch_bounds__(256) void stft_logpower_kernel(const float* __restrict__ wave, int len, int W,
+typedef int stft_i32x4 __attribute__((ext_vector_type(4)));
+__device__ f32x4 stft_buffer_load_f32x4(stft_i32x4 srsrc, int voffset, int soffset, int aux) __asm(
+    "llvm.amdgcn.raw.buffer.load.v4f32");
+
+__global__ __launch_bounds__(512) void stft_logpower_kernel(const float* __restrict__ wave, int len, int W,
                                                             const float* __restrict__ tw, float* __restrict__ spec,
                                                             float eps) {
   __shared__ __attribute__((aligned(16))) float fr[(STFT_FR + 1) * STFT_PITCH];
   const int seg = blockIdx.y, t0 = blockIdx.x * STFT_FR;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int lrow = lane & 31, lhalf = lane >> 5;
-  const int b0 = blockIdx.z * 128 + wv * 32;
-  const float* y = wave + (size_t)seg * len;
-  const int g0 = (t0 - 1) * 120;
-  for (int i = tid; i < (STFT_FR + 1) * 120; i += 256) {
-    const int r = i / 120, c = i - r * 120;
-    const int g = g0 + i;
-    fr[r * STFT_PITCH + c] = (g >= 0 && g < len) ? y[g] : 0.f;
+  const int b0 = wv * 32;
+  {
+    // this segment's samples as a raw buffer: offsets in front of sample 0 (negative -> huge unsigned) and behind sample
+    // len - 1 are out of range, per dword -> zeros (librosa's centre padding, reference dataset.py:487-489)
+    union {
+      stft_i32x4 v;
+      struct {
+        const void* p;
+        unsigned range, cfg;
+      } d;
+    } u;
+    u.d.p = wave + (size_t)seg * len;
+    u.d.range = (unsigned)len * 4u;
+    u.d.cfg = 0x00020000u;
+    stft_i32x4 rs;
+    rs.x = __builtin_amdgcn_readfirstlane(u.v.x);
+    rs.y = __builtin_amdgcn_readfirstlane(u.v.y);
+    rs.z = __builtin_amdgcn_readfirstlane(u.v.z);
+    rs.w = __builtin_amdgcn_readfirstlane(u.v.w);
+    const int g0 = (t0 - 1) * 120;     // first staged sample (a multiple of 4: a 16-B group never straddles sample 0)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i4 = tid + 512 * q;    // 16-B group of the 65 x 120 span (30 groups per hop row)
+      if (i4 < (STFT_FR + 1) * 30) {
+        const int r = (i4 * 2185) >> 16, c4 = i4 - r * 30;   // i4 / 30 for i4 < 2048
+        const f32x4 v = stft_buffer_load_f32x4(rs, (g0 + i4 * 4) * 4, 0, 0);
+        *reinterpret_cast<float4*>(&fr[r * STFT_PITCH + c4 * 4]) = make_float4(v.x, v.y, v.z, v.w);
+      }
+    }
   }
   // twiddle fragment of tap group kg: 16 B at [part][kg][b0 + lrow][4 * lhalf]
   const float4* twc = reinterpret_cast<const float4*>(tw) + ((size_t)(b0 + lrow) * 2 + lhalf);
@@ -71,12 +102,14 @@ __global__ __launch_bounds__(256) void stft_logpower_kernel(const float* __restr
 #undef STFT_STEP
   }
   float* o = spec + (size_t)seg * STFT_BINS * W;
+  const float ln2 = 0.6931471805599453f;
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
     const int bin = b0 + 8 * (e >> 2) + 4 * lhalf + (e & 3);
     const int ta = t0 + lrow, tb = t0 + 32 + lrow;
-    if (ta < W) o[(size_t)bin * W + ta] = logf(re0[e] * re0[e] + im0[e] * im0[e] + eps);
-    if (tb < W) o[(size_t)bin * W + tb] = logf(re1[e] * re1[e] + im1[e] * im1[e] + eps);
+    // |X|^2 + eps >= 1e-6 is a normal number: v_log_f32 (log2, 1 ulp) * ln 2
+    if (ta < W) o[(size_t)bin * W + ta] = __builtin_amdgcn_logf(fmaf(re0[e], re0[e], fmaf(im0[e], im0[e], eps))) * ln2;
+    if (tb < W) o[(size_t)bin * W + tb] = __builtin_amdgcn_logf(fmaf(re1[e], re1[e], fmaf(im1[e], im1[e], eps))) * ln2;
   }
 }
 
@@ -104,9 +137,9 @@ int tbn_stft_make_twiddle(float* host) {
 int tbn_stft_logpower(const float* wave, int nseg, int len, const float* twiddle, float* spec, float eps,
                       void* stream) {
   TBN_REQUIRE(wave && twiddle && spec && nseg > 0 && len > 0, "stft_logpower: bad argument");
-  TBN_REQUIRE(nseg <= 65535, "stft_logpower: too many segments per call");
+  TBN_REQUIRE(nseg <= 65535 && (size_t)len * 4 < (1ull << 31), "stft_logpower: too many segments / too long a waveform per call");
   const int W = 1 + (len - 1) / 120;
-  hipLaunchKernelGGL(stft_logpower_kernel, dim3(cdiv(W, STFT_FR), nseg, 2), dim3(256), 0, (hipStream_t)stream, wave,
+  hipLaunchKernelGGL(stft_logpower_kernel, dim3(cdiv(W, STFT_FR), nseg), dim3(512), 0, (hipStream_t)stream, wave,
                      len, W, twiddle, spec, eps);
   TBN_CHECK_LAUNCH("stft_logpower");
   return TBN_OK;

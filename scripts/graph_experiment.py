@@ -1,5 +1,6 @@
 """Experiment: capture the whole config-4 train step (fwd + loss + bwd + clip + SGD) in one HIP graph and replay it."""
-import os, sys, time, torch
+import faulthandler, os, sys, time, torch
+faulthandler.enable(all_threads=True)      # a SIGSEGV prints the Python stack of every thread (autograd thread included)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from attention_based_tbn_amd.config import load_config, get_modality
@@ -43,9 +44,24 @@ with torch.cuda.stream(s):
 torch.cuda.current_stream().wait_stream(s)
 g = torch.cuda.CUDAGraph()
 opt.zero_grad(set_to_none=True)
+# during the capture every backbone entry point announces itself on stderr before and after the call: if the process
+# dies inside the capture the last line names the call (forward / backward of which plan), if it dies after the last
+# "<-" the fault is in the end-of-capture processing
+from attention_based_tbn_amd import _lib as _tl
+from attention_based_tbn_amd.core.models import bn_inception as _bi
+_orig_call = _tl.call
+def _traced(name, *a):
+    if name.startswith("tbn_backbone_"):
+        print("[capture] -> %s plan=%x" % (name, getattr(a[0], "value", 0) or 0), file=sys.stderr, flush=True)
+    _orig_call(name, *a)
+    if name.startswith("tbn_backbone_"):
+        print("[capture] <- %s" % name, file=sys.stderr, flush=True)
+_bi.call = _traced
 try:
     with torch.cuda.graph(g):
         static_loss = step()
+        print("[capture] step() returned: leaving the capture context (hipStreamEndCapture)", file=sys.stderr, flush=True)
+    _bi.call = _orig_call
     print("captured", flush=True)
     for _ in range(3): g.replay()
     print("graph replay %.3f ms/step  loss %.4f" % (timeit(g.replay, 30), static_loss.item()), flush=True)

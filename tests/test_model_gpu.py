@@ -456,9 +456,10 @@ def test_config4_full_batch_train_step_vs_oracle():
     sibling pairs, split-K tiles, 160-wide weight-gradient tiles only win at this size) -- one training step (reference
     loop body core/tools/train.py:76-81) against the CPU oracle with the same weights and full-size synthetic inputs:
     logits, losses and every BN running statistic within 1e-3; the gradient norm and each backbone's conv weight
-    gradients against the oracle's own fp32 step (relative L2 < 2e-2, cosine > 0.999: at 96 frames per BatchNorm the
-    last-bit ReLU / max-pool decision flips that dominate the small-batch gradient tests average out).  The oracle step
-    takes about a minute on the GPU box's host cores."""
+    gradients against the oracle's own fp32 step (relative L2 < 3e-2, cosine > 0.999; observed 0.6e-2 ... 1.2e-2: two
+    fp32 runs of this graph differ by their last-bit ReLU / max-pool decisions -- with the decisions pinned the same
+    gradients agree to 1e-4, test_backbone_all_layer_grads_forced_decisions -- and the reference's own fp32 gradients sit
+    1e-3 ... 7e-2 from an fp64 run on the small golden cases).  The oracle step takes ~85 s on the GPU box's host cores."""
     import ctypes as C
     import time
     from attention_based_tbn_amd._lib import lib
@@ -535,8 +536,9 @@ def test_config4_full_batch_train_step_vs_oracle():
         want = torch.cat([ograds[k].reshape(-1) for k in sorted(grads) if k.startswith(f"Base_{m}.") and k.endswith(".weight")
                           and "_bn." not in k])
         e = l2_err(got, want)
+        print("R = 96 parity: %s conv weight gradients relative L2 %.2e, cosine %.6f" % (m, e, cosine(got, want)))
         worst = max(worst, (e, m))
-        assert e < 2e-2 and cosine(got, want) > 0.999, (m, e)
+        assert e < 3e-2 and cosine(got, want) > 0.999, (m, e)
     gn = torch.sqrt(sum((v.double() ** 2).sum() for v in grads.values()))
     ogn = torch.sqrt(sum((v.double() ** 2).sum() for k, v in ograds.items() if k in grads))
     assert abs(float(gn) - float(ogn)) < 2e-2 * float(ogn), (float(gn), float(ogn))
