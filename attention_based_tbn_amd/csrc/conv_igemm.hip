@@ -94,6 +94,28 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[MT][
   const bool tile_full = (m0 + BM <= p.M);
   constexpr bool scatter = (EPI == 3);  // strided data-gradient phase
   constexpr bool SUMS = (EPI == 1) || RED;   // (the K loop ends with a barrier: `red` may overlay the tiles)
+  // VALU diet of the epilogue (round 3): the static instruction count of a <1,1> data-gradient tile with the reduce was
+  // ~650 VALU (~450 of them here) against 16 MFMAs per K-step -- 2.2 VALU per MFMA over an 18-step tile, 6.8 over the
+  // 6 steps of the short-K 1x1 groups -- because block-uniform run-time cases (ragged last M tile, accumulate, ReLU,
+  // bias) were evaluated per element with selects.  A full tile without those takes the LEAN loop: per element one
+  // store (+ 2 VALU for the statistics, + 6 for the reduce); everything else keeps the general loop.
+  const bool lean = tile_full && !scatter &&
+                    (EPI != 0 || ((p.flags & (CONV_FLAG_ACCUM | CONV_FLAG_RELU)) == 0 && p.bias == nullptr));
+  // strided data-gradient phase: output pixel of each tile row, decoded ONCE per row into LDS (was: two magic-number
+  // divisions per ELEMENT, ~25 VALU x 16 elements x NT sub-tiles per lane)
+  unsigned* opix_tab = reinterpret_cast<unsigned*>(lds + 2 * 4 * BN);
+  if (scatter) {
+    if (tid < BM) {
+      const int m = m0 + tid;
+      const uint32_t n = fdiv((uint32_t)m, p.div_ohw);
+      const uint32_t rem = (uint32_t)m - n * p.div_ohw.d;
+      const uint32_t a = fdiv(rem, p.div_ow);
+      const uint32_t b = rem - a * p.div_ow.d;
+      const unsigned opix = (unsigned)(((int)n * p.OH + ((int)a * p.out_sy + p.out_oy)) * p.OW + ((int)b * p.out_sx + p.out_ox));
+      opix_tab[tid] = m < p.M ? opix : 0xffffffffu;
+    }
+    __syncthreads();
+  }
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     const int colb = n0 + j * 32;
@@ -144,6 +166,38 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[MT][
       }
     }
     float s1 = 0.f, s2 = 0.f;
+    if (lean) {
+      // columns without a BN layer behind them (or beyond it) keep b_sc = b_sh = 0: fma(y, 0, 0) > 0 is false -> g = 0
+      const float b_nmr = -b_mu * b_rs;       // xhat = fma(y, rstd, -mean * rstd)
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const unsigned vbase = col_ok ? (unsigned)(mrow0 + i * 32) * (unsigned)old * 4u + col_off : TBN_OOB;
+        const unsigned ybase = (RED && red_on && col_ok) ? (unsigned)(mrow0 + i * 32) * (unsigned)yld * 4u + ycol_off : TBN_OOB;
+        float yv[16];
+        if (RED) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e)
+            yv[e] = tbn_llvm_buffer_load_f32(y_rsrc, (int)ybase, (int)((unsigned)((8 * (e >> 2) + (e & 3)) * yld) * 4u), 0);
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int dm = 8 * (e >> 2) + (e & 3);
+          float v = acc[i][j][e];
+          if (EPI == 1) {
+            s1 += v;
+            s2 = fmaf(v, v, s2);
+          } else if (EPI == 2) {
+            if (!raw) v = fmaxf(fmaf(v, sc, sh), 0.f);
+          }
+          tbn_llvm_buffer_store_f32(v, o_rsrc, (int)vbase, (int)((unsigned)(dm * old) * 4u), 0);
+          if (RED) {
+            const float g = fmaf(yv[e], b_sc, b_sh) > 0.f ? v : 0.f;
+            s1 += g;
+            s2 = fmaf(g, fmaf(yv[e], b_rs, b_nmr), s2);
+          }
+        }
+      }
+    } else {
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
       const unsigned vbase = col_ok ? (unsigned)(mrow0 + i * 32) * (unsigned)old * 4u + col_off : TBN_OOB;
@@ -163,16 +217,12 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[MT][
         unsigned voff = vbase, soff = (unsigned)(dm * old) * 4u;
         unsigned yvoff = ybase, ysoff = (unsigned)(dm * yld) * 4u;
         if (scatter) {
-          const int m = mrow0 + i * 32 + dm;
-          const uint32_t n = fdiv((uint32_t)m, p.div_ohw);
-          const uint32_t rem = (uint32_t)m - n * p.div_ohw.d;
-          const uint32_t a = fdiv(rem, p.div_ow);
-          const uint32_t b = rem - a * p.div_ow.d;
-          const unsigned opix = (unsigned)(((int)n * p.OH + ((int)a * p.out_sy + p.out_oy)) * p.OW + ((int)b * p.out_sx + p.out_ox));
-          voff = (m < p.M && col_ok) ? opix * (unsigned)old * 4u + col_off : TBN_OOB;
+          const unsigned opix = opix_tab[wave * 32 * MT + i * 32 + 4 * lhalf + dm];   // 0xffffffff: row >= M
+          const bool ok = opix != 0xffffffffu && col_ok;
+          voff = ok ? __umul24(opix, (unsigned)old * 4u) + col_off : TBN_OOB;
           soff = 0u;
           if (RED) {
-            yvoff = (m < p.M && col_ok && red_on) ? opix * (unsigned)yld * 4u + ycol_off : TBN_OOB;
+            yvoff = (ok && red_on) ? __umul24(opix, (unsigned)yld * 4u) + ycol_off : TBN_OOB;
             ysoff = 0u;
           }
         } else if (!tile_full) {
@@ -193,6 +243,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[MT][
           s2 = fmaf(g, (yv - b_mu) * b_rs, s2);
         }
       }
+    }
     }
     if (SUMS) {
       s1 += __shfl_xor(s1, 32);
@@ -269,10 +320,23 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& p, const int bid, f
   const int c4 = tid & 7, r0 = tid >> 3;
   unsigned a_off[AR];   // byte offset of the row's (n, iy0, ix0) pixel (ROWMODE: out of range for rows >= M)
   unsigned a_mask[AR];  // bit t: tap t of this row lies inside the image (unused in ROWMODE: the border is physical)
-  {
+  // Row setup (VALU diet, round 3).  Eight threads (c4 = 0..7) share each tile row: decoding the rows per thread ran the
+  // two magic divisions and the tap masks 8x per row, ~35 VALU x 4*MT rows per thread.  Now a pointwise launch (1x1,
+  // stride 1, no padding: every fused 1x1 group) needs no decode at all -- the input pixel IS the output row -- and
+  // every other launch decodes each row ONCE (thread t < BM takes row t) into an LDS table the threads then read.
+  const bool pointwise = !ROWMODE && p.ntaps == 1 && p.in_sy == 1 && p.in_sx == 1 && p.ty0 == 0 && p.tx0 == 0 &&
+                         p.OHs == p.H && p.OWs == p.W;
+  if (pointwise) {
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
       const int m = m0 + r0 + 32 * i;
+      a_off[i] = (unsigned)m * (unsigned)p.in_ld * 4u;
+      a_mask[i] = m < p.M ? 1u : 0u;
+    }
+  } else {
+    unsigned* rowtab = reinterpret_cast<unsigned*>(lds);   // [BM][2]: the tiles are not staged yet
+    if (tid < BM) {
+      const int m = m0 + tid;
       unsigned mask = 0;
       unsigned off = ROWMODE ? TBN_OOB : 0u;
       if (m < p.M) {
@@ -299,9 +363,17 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& p, const int bid, f
             if ((yb >> r) & 1u) mask |= xb << (r * p.tnx);
         }
       }
-      a_off[i] = off;
-      a_mask[i] = mask;
+      rowtab[2 * tid] = off;
+      rowtab[2 * tid + 1] = mask;
     }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+      const uint2 e = *reinterpret_cast<const uint2*>(&rowtab[2 * (r0 + 32 * i)]);
+      a_off[i] = e.x;
+      a_mask[i] = e.y;
+    }
+    __syncthreads();   // everyone has read the table before the first tile store overwrites it
   }
 
   if (ABL(128)) {  // ablation: exit after the per-row setup
@@ -656,32 +728,44 @@ __device__ __forceinline__ void conv_dma_body(const ConvP& p, const int bid, flo
 
   const int rl = lane >> 3, slot = lane & 7;   // row within the 8-row group / 16-B slot this lane's bytes land in
   unsigned a_off[AR], a_mask[AR];
+  {
+    // each tile row is decoded once (thread t < BM takes row t) into an LDS table -- eight lanes share a row; decoding
+    // per lane repeated the two magic divisions and the tap masks 8x (see conv_igemm_body)
+    unsigned* rowtab = reinterpret_cast<unsigned*>(lds);   // [BM][2]: no DMA has been issued yet
+    if (tid < BM) {
+      const int m = m0 + tid;
+      unsigned mask = 0;
+      int off = 0;
+      if (m < p.M) {
+        const uint32_t n = fdiv((uint32_t)m, p.div_ohw);
+        const uint32_t rem = (uint32_t)m - n * p.div_ohw.d;
+        const uint32_t a = fdiv(rem, p.div_ow);
+        const uint32_t b = rem - a * p.div_ow.d;
+        const int iy0 = (int)a * p.in_sy, ix0 = (int)b * p.in_sx;
+        unsigned yb = 0, xb = 0;
 #pragma unroll
-  for (int i = 0; i < AR; ++i) {
-    const int r = (wave * AR + i) * 8 + rl;    // tile row
-    const int m = m0 + r;
-    unsigned mask = 0;
-    int off = 0;
-    if (m < p.M) {
-      const uint32_t n = fdiv((uint32_t)m, p.div_ohw);
-      const uint32_t rem = (uint32_t)m - n * p.div_ohw.d;
-      const uint32_t a = fdiv(rem, p.div_ow);
-      const uint32_t b = rem - a * p.div_ow.d;
-      const int iy0 = (int)a * p.in_sy, ix0 = (int)b * p.in_sx;
-      unsigned yb = 0, xb = 0;
+        for (int rr = 0; rr < 3; ++rr)
+          if (rr < p.tny && (unsigned)(iy0 + p.ty0 + rr) < (unsigned)p.H) yb |= 1u << rr;
 #pragma unroll
-      for (int rr = 0; rr < 3; ++rr)
-        if (rr < p.tny && (unsigned)(iy0 + p.ty0 + rr) < (unsigned)p.H) yb |= 1u << rr;
+        for (int c = 0; c < 3; ++c)
+          if (c < p.tnx && (unsigned)(ix0 + p.tx0 + c) < (unsigned)p.W) xb |= 1u << c;
 #pragma unroll
-      for (int c = 0; c < 3; ++c)
-        if (c < p.tnx && (unsigned)(ix0 + p.tx0 + c) < (unsigned)p.W) xb |= 1u << c;
-#pragma unroll
-      for (int rr = 0; rr < 3; ++rr)
-        if ((yb >> rr) & 1u) mask |= xb << (rr * p.tnx);
-      off = (((int)n * p.H + iy0) * p.W + ix0) * p.in_ld * 4 + ((slot ^ ((r >> 1) & 7)) << 4);   // swizzled source chunk
+        for (int rr = 0; rr < 3; ++rr)
+          if ((yb >> rr) & 1u) mask |= xb << (rr * p.tnx);
+        off = (((int)n * p.H + iy0) * p.W + ix0) * p.in_ld * 4;
+      }
+      rowtab[2 * tid] = (unsigned)off;
+      rowtab[2 * tid + 1] = mask;
     }
-    a_off[i] = (unsigned)off;
-    a_mask[i] = mask;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+      const int r = (wave * AR + i) * 8 + rl;    // tile row
+      const uint2 e = *reinterpret_cast<const uint2*>(&rowtab[2 * r]);
+      a_off[i] = e.x + (unsigned)((slot ^ ((r >> 1) & 7)) << 4);   // swizzled source chunk (masked rows never load)
+      a_mask[i] = e.y;
+    }
+    __syncthreads();   // the table is dead: the first DMA may overwrite it
   }
   unsigned b_voff[NT];
 #pragma unroll
@@ -837,30 +921,42 @@ __device__ __forceinline__ void conv_sk4_body(const ConvP& p, const int bid, flo
 
   const int c4 = lane & 7, r0 = lane >> 3;
   unsigned a_off[AR], a_mask[AR];
+  {
+    // the four waves stage the SAME 32*MT rows (different K chunks): decoded once per row into an LDS table instead of
+    // by every lane of every wave (32x redundant: ~35 VALU x 4*MT rows per lane)
+    unsigned* rowtab = reinterpret_cast<unsigned*>(lds);   // [BM][2]: nothing is staged yet
+    if (tid < BM) {
+      const int m = m0 + tid;
+      unsigned mask = 0, off = 0;
+      if (m < p.M) {
+        const uint32_t n = fdiv((uint32_t)m, p.div_ohw);
+        const uint32_t rem = (uint32_t)m - n * p.div_ohw.d;
+        const uint32_t a = fdiv(rem, p.div_ow);
+        const uint32_t b = rem - a * p.div_ow.d;
+        const int iy0 = (int)a * p.in_sy, ix0 = (int)b * p.in_sx;
+        unsigned yb = 0, xb = 0;
 #pragma unroll
-  for (int i = 0; i < AR; ++i) {
-    const int m = m0 + r0 + 8 * i;
-    unsigned mask = 0, off = 0;
-    if (m < p.M) {
-      const uint32_t n = fdiv((uint32_t)m, p.div_ohw);
-      const uint32_t rem = (uint32_t)m - n * p.div_ohw.d;
-      const uint32_t a = fdiv(rem, p.div_ow);
-      const uint32_t b = rem - a * p.div_ow.d;
-      const int iy0 = (int)a * p.in_sy, ix0 = (int)b * p.in_sx;
-      unsigned yb = 0, xb = 0;
+        for (int r = 0; r < 3; ++r)
+          if (r < p.tny && (unsigned)(iy0 + p.ty0 + r) < (unsigned)p.H) yb |= 1u << r;
+        off = (unsigned)((((int)n * p.H + iy0) * p.W + ix0) * p.in_ld * 4);
 #pragma unroll
-      for (int r = 0; r < 3; ++r)
-        if (r < p.tny && (unsigned)(iy0 + p.ty0 + r) < (unsigned)p.H) yb |= 1u << r;
-      off = (unsigned)((((int)n * p.H + iy0) * p.W + ix0) * p.in_ld * 4);
+        for (int c = 0; c < 3; ++c)
+          if (c < p.tnx && (unsigned)(ix0 + p.tx0 + c) < (unsigned)p.W) xb |= 1u << c;
 #pragma unroll
-      for (int c = 0; c < 3; ++c)
-        if (c < p.tnx && (unsigned)(ix0 + p.tx0 + c) < (unsigned)p.W) xb |= 1u << c;
-#pragma unroll
-      for (int r = 0; r < 3; ++r)
-        if ((yb >> r) & 1u) mask |= xb << (r * p.tnx);
+        for (int r = 0; r < 3; ++r)
+          if ((yb >> r) & 1u) mask |= xb << (r * p.tnx);
+      }
+      rowtab[2 * tid] = off;
+      rowtab[2 * tid + 1] = mask;
     }
-    a_off[i] = off;
-    a_mask[i] = mask;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+      const uint2 e = *reinterpret_cast<const uint2*>(&rowtab[2 * (r0 + 8 * i)]);
+      a_off[i] = e.x;
+      a_mask[i] = e.y;
+    }
+    __syncthreads();   // the table is dead: the waves' private tiles may overwrite it
   }
   unsigned b_voff[BR];
 #pragma unroll
@@ -1964,7 +2060,9 @@ int tbn_launch_weight_flip_transpose(const float* w, float* wt, int Cout, int ta
 // 32 x 32 (co, ci) tile of every filter tap.
 __global__ __launch_bounds__(256) void weight_flip_transpose_all_kernel(const float* __restrict__ w,
                                                                         float* __restrict__ wt, FlipTab tab) {
-  __shared__ float tile[32][33];
+  // all taps of the tile are loaded first (up to 36 loads in flight per thread), ONE barrier, then all are written:
+  // the former tap-by-tap form (two barriers per 4-KB tap slice) ran the 40 MB of a backbone at ~1 TB/s
+  __shared__ float tile[9][32][33];
   int lo = 0, hi = tab.n;
   while (hi - lo > 1) {
     const int mid = (lo + hi) >> 1;
@@ -1981,18 +2079,19 @@ __global__ __launch_bounds__(256) void weight_flip_transpose_all_kernel(const fl
   const float* wl = w + tab.w_off[l];
   float* wtl = wt + tab.w_off[l];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  for (int tap = 0; tap < taps; ++tap) {
+  for (int tap = 0; tap < taps; ++tap)
+#pragma unroll
     for (int i = ty; i < 32; i += 8) {
       const int co = co0 + i, ci = ci0 + tx;
-      tile[i][tx] = (co < Cout && ci < Cin) ? wl[((size_t)co * taps + tap) * Cin + ci] : 0.f;
+      tile[tap][i][tx] = (co < Cout && ci < Cin) ? wl[((size_t)co * taps + tap) * Cin + ci] : 0.f;
     }
-    __syncthreads();
+  __syncthreads();
+  for (int tap = 0; tap < taps; ++tap)
+#pragma unroll
     for (int i = ty; i < 32; i += 8) {
       const int ci = ci0 + i, co = co0 + tx;
-      if (ci < Cin && co < Cout) wtl[((size_t)ci * taps + (taps - 1 - tap)) * Cout + co] = tile[tx][i];
+      if (ci < Cin && co < Cout) wtl[((size_t)ci * taps + (taps - 1 - tap)) * Cout + co] = tile[tap][tx][i];
     }
-    __syncthreads();
-  }
 }
 
 int tbn_launch_weight_flip_transpose_all(const float* w, float* wt, const FlipTab& tab, hipStream_t st) {

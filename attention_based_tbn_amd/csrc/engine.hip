@@ -1335,6 +1335,18 @@ int tbn_backbone_backward(const tbn_backbone_plan* P, const float* dfeatures, co
     }
   }
   TBN_REQUIRE(aux == nullptr || (PM->n_ev == NE && (int)P->convs.size() < NE), "backbone_backward: event pool too small");
+  if (aux != nullptr) {
+    // Forking the weight-gradient stream from a stream that is itself a forked member of a capture (the modality streams
+    // of a whole-step hipGraph) makes hipStreamEndCapture of ROCm 7.x (hip::Stream::EndCapture) recurse into itself until
+    // the stack overflows -- a SIGSEGV after every call of the step has returned (profiles/r03_graph_capture_multi_aux_rocgdb.log).
+    // Whether `st` is the capture's origin (a single-level fork captures fine) cannot be queried: refuse the combination.
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) {
+      tbn_set_error("backbone_backward: aux_stream inside a stream capture is not supported (nested capture forks overflow "
+                    "the stack of hipStreamEndCapture in ROCm 7.x): capture with aux_stream = NULL");
+      return TBN_ERR_UNSUPPORTED;
+    }
+  }
   // events 0..NE-2 fork (launch stream -> aux), the last one is the join: whatever path leaves this function, the aux
   // stream is joined back (a fork left open would also break hipGraph capture of a step)
   AuxJoin join{st, aux, aux != nullptr ? PM->ev[NE - 1] : nullptr};

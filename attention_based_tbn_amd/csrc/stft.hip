@@ -6,17 +6,20 @@
 // bins are a dense 256 x 240 real DFT: X[k] = sum_j hann[j] * y[120 t - 120 + j] * e^{-2 pi i (j+135) k / 511}.
 // That is a [bins x taps] x [taps x frames] contraction -> fp32 MFMA (32x32x2), 2 * 2 * 256 * 240 FLOP per frame.
 //
-// Workgroup = ALL 256 bins x 64 frames of one segment: 8 waves x 32 bins; re and im of 2 frame tiles = 4 accumulators
-// per wave (round 2: two workgroups of 4 waves each re-staged the same frames for half the bins).
+// Workgroup = 64 frames of one segment x ALL 256 bins (8 waves x 32 bins) or x 128 bins (4 waves, two workgroups per
+// frame block); re and im of 2 frame tiles = 4 accumulators per wave.  The 8-wave form stages the frames once per
+// block, but a launch is only (frame blocks x segments) workgroups: config 4's 96 segments x 4 blocks = 384 leave the 256
+// CUs with 1 or 2 workgroups each (measured: 81 us against 72 us for the 768 balanced 4-wave workgroups), so the
+// launcher takes the 8-wave form only when its grid fills the CUs evenly (e.g. 192 segments: 149 -> 122 us).
 //   * frames (B operand): hop = 120, 240 taps -> consecutive frames overlap by half.  The RAW samples of the 64
 //     frames (65 hop rows of 120) are staged ONCE per workgroup in LDS with rows padded to 124 floats: frame f, tap j
 //     lives at (f + j / 120) * 124 + j % 120, no im2col copy, and a lane's four consecutive taps are one conflict-free
 //     ds_read_b128 (lane stride 496 B -> 16 distinct 16-B slots per 16-lane group).  The 65 rows are one contiguous
-//     span of the waveform: staged with 16-B buffer loads (1950 of them per workgroup, 4 per thread) whose hardware
+//     span of the waveform: staged with 16-B buffer loads (1950 of them per workgroup, 4 or 8 per thread) whose hardware
 //     range check supplies the zero padding in front of the first and behind the last sample;
 //   * twiddles (A operand): the window is folded into the table, stored [cos | -sin][tap / 8][bin][tap % 8]: the
 //     fragment of 8 taps x 32 bins is ONE fully coalesced 1-KB load per wave (the table is 480 KB, shared by every
-//     workgroup: L2 resident), prefetched one 8-tap group ahead; each load feeds 8 MFMAs;
+//     workgroup: L2 resident), prefetched two 8-tap groups ahead; each load feeds 8 MFMAs;
 //   * k is permuted identically for A and B (lane half h holds taps 4h..4h+3 of the group) so one 16-B fragment
 //     feeds four MFMAs; accumulators put frames on lanes -> the (256, W) freq-major rows are written 128 B contiguous;
 //   * log(|X|^2 + eps) with the hardware logarithm (v_log_f32, 1 ulp): 3 VALU instructions per output instead of the
@@ -37,14 +40,15 @@ typedef int stft_i32x4 __attribute__((ext_vector_type(4)));
 __device__ f32x4 stft_buffer_load_f32x4(stft_i32x4 srsrc, int voffset, int soffset, int aux) __asm(
     "llvm.amdgcn.raw.buffer.load.v4f32");
 
-__global__ __launch_bounds__(512) void stft_logpower_kernel(const float* __restrict__ wave, int len, int W,
-                                                            const float* __restrict__ tw, float* __restrict__ spec,
-                                                            float eps) {
+template <int NW>   // waves per workgroup: 8 (all 256 bins) or 4 (128 bins, blockIdx.z picks the half)
+__global__ __launch_bounds__(64 * NW) void stft_logpower_kernel(const float* __restrict__ wave, int len, int W,
+                                                                const float* __restrict__ tw, float* __restrict__ spec,
+                                                                float eps) {
   __shared__ __attribute__((aligned(16))) float fr[(STFT_FR + 1) * STFT_PITCH];
   const int seg = blockIdx.y, t0 = blockIdx.x * STFT_FR;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int lrow = lane & 31, lhalf = lane >> 5;
-  const int b0 = wv * 32;
+  const int b0 = (NW == 8 ? 0 : blockIdx.z * 128) + wv * 32;
   {
     // this segment's samples as a raw buffer: offsets in front of sample 0 (negative -> huge unsigned) and behind sample
     // len - 1 are out of range, per dword -> zeros (librosa's centre padding, reference dataset.py:487-489)
@@ -65,8 +69,8 @@ __global__ __launch_bounds__(512) void stft_logpower_kernel(const float* __restr
     rs.w = __builtin_amdgcn_readfirstlane(u.v.w);
     const int g0 = (t0 - 1) * 120;     // first staged sample (a multiple of 4: a 16-B group never straddles sample 0)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int i4 = tid + 512 * q;    // 16-B group of the 65 x 120 span (30 groups per hop row)
+    for (int q = 0; q < 2048 / (64 * NW); ++q) {
+      const int i4 = tid + 64 * NW * q;    // 16-B group of the 65 x 120 span (30 groups per hop row)
       if (i4 < (STFT_FR + 1) * 30) {
         const int r = (i4 * 2185) >> 16, c4 = i4 - r * 30;   // i4 / 30 for i4 < 2048
         const f32x4 v = stft_buffer_load_f32x4(rs, (g0 + i4 * 4) * 4, 0, 0);
@@ -80,14 +84,20 @@ __global__ __launch_bounds__(512) void stft_logpower_kernel(const float* __restr
   f32x16 re0, im0, re1, im1;
 #pragma unroll
   for (int e = 0; e < 16; ++e) re0[e] = im0[e] = re1[e] = im1[e] = 0.f;
-  float4 ac = twc[0], as = twc[part4];
+  // twiddle fragments are prefetched TWO tap groups ahead: one group is 16 MFMAs (~1.3 us with three waves per SIMD),
+  // about the L2 latency under load -- a distance of one group left the loads exposed
+  float4 ac[2], as[2];
+  ac[0] = twc[0];
+  as[0] = twc[part4];
+  ac[1] = twc[(size_t)STFT_BINS * 2];
+  as[1] = twc[part4 + (size_t)STFT_BINS * 2];
   __syncthreads();
 #pragma unroll 2
   for (int kg = 0; kg < STFT_KG; ++kg) {
-    const float4 c = ac, s = as;
-    if (kg + 1 < STFT_KG) {
-      ac = twc[(size_t)(kg + 1) * STFT_BINS * 2];
-      as = twc[part4 + (size_t)(kg + 1) * STFT_BINS * 2];
+    const float4 c = ac[kg & 1], s = as[kg & 1];
+    if (kg + 2 < STFT_KG) {
+      ac[kg & 1] = twc[(size_t)(kg + 2) * STFT_BINS * 2];
+      as[kg & 1] = twc[part4 + (size_t)(kg + 2) * STFT_BINS * 2];
     }
     const int tap0 = kg * 8 + 4 * lhalf;
     const int off = (lrow + (tap0 >= 120 ? 1 : 0)) * STFT_PITCH + (tap0 >= 120 ? tap0 - 120 : tap0);
@@ -139,8 +149,14 @@ int tbn_stft_logpower(const float* wave, int nseg, int len, const float* twiddle
   TBN_REQUIRE(wave && twiddle && spec && nseg > 0 && len > 0, "stft_logpower: bad argument");
   TBN_REQUIRE(nseg <= 65535 && (size_t)len * 4 < (1ull << 31), "stft_logpower: too many segments / too long a waveform per call");
   const int W = 1 + (len - 1) / 120;
-  hipLaunchKernelGGL(stft_logpower_kernel, dim3(cdiv(W, STFT_FR), nseg), dim3(512), 0, (hipStream_t)stream, wave,
-                     len, W, twiddle, spec, eps);
+  // the 8-wave form when (frame blocks x segments) workgroups load the 256 CUs evenly (>= 87 % of whole rounds)
+  const int blocks = cdiv(W, STFT_FR) * nseg, rounds = cdiv(blocks, 256);
+  if (blocks * 8 >= rounds * 256 * 7)
+    hipLaunchKernelGGL(stft_logpower_kernel<8>, dim3(cdiv(W, STFT_FR), nseg), dim3(512), 0, (hipStream_t)stream, wave, len,
+                       W, twiddle, spec, eps);
+  else
+    hipLaunchKernelGGL(stft_logpower_kernel<4>, dim3(cdiv(W, STFT_FR), nseg, 2), dim3(256), 0, (hipStream_t)stream, wave,
+                       len, W, twiddle, spec, eps);
   TBN_CHECK_LAUNCH("stft_logpower");
   return TBN_OK;
 }

@@ -76,7 +76,8 @@ typedef struct {
   float* dbeta;               /* may be NULL */
   int bn_grad_layers;         /* 0 none, 1 first BN only ("partialbn", model.py:164-176), 2 all */
   void* aux_stream;           /* optional second hipStream_t (caller-owned): weight-gradient GEMMs run on it,
-                                 overlapping the data-gradient / BN-backward chain; joined before return.  NULL = serial */
+                                 overlapping the data-gradient / BN-backward chain; joined before return.  NULL = serial.
+                                 Not inside a stream capture (TBN_ERR_UNSUPPORTED): nested capture forks crash ROCm 7.x */
 } tbn_backbone_grads;
 
 int tbn_backbone_plan_create(int in_channels, int frames, int height, int width, tbn_backbone_plan** plan);
