@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Aggregate a rocprofv3 --pmc counter_collection.csv of scripts/layer_profile.py by kernel name
-(last training iteration only: from the last nchw_to_s2d_pad dispatch on)."""
+(last training iteration only: from the last input-layout (nchw_to_*_pad) dispatch on)."""
 import csv, re, sys
 from collections import defaultdict, OrderedDict
 
@@ -15,7 +15,7 @@ for r in rows:
                             "t": int(r["End_Timestamp"]) - int(r["Start_Timestamp"])})
     e[r["Counter_Name"]] = float(r["Counter_Value"])
 ids = list(disp)
-start = max(i for i in ids if disp[i]["k"].startswith("nchw_to_s2d_pad"))
+start = max(i for i in ids if disp[i]["k"].startswith(("nchw_to_s2d_pad", "nchw_to_nhwc_pad")))
 agg = defaultdict(lambda: defaultdict(float))
 for i in ids:
     if i < start: continue
