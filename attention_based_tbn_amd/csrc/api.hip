@@ -49,6 +49,7 @@ struct ProfRec {
   int name;
   double flops, bytes;
   hipEvent_t a, b;
+  bool used;      // a launch took the events (hipExtLaunchKernelGGL wrote the kernel's begin / end timestamps into them)
 };
 struct ProfAgg {
   long launches = 0;
@@ -58,6 +59,8 @@ std::mutex g_prof_mu;
 bool g_prof_on = false;
 bool g_prof_layers = false;   // enable(2): key = "kernel | layer label"
 std::string g_prof_label;
+thread_local const char* g_prof_prefix = nullptr;   // "linear: " while a head Linear entry point launches (bench.py keeps
+                                                    // the BN-Inception conv stage and the head GEMMs apart)
 std::vector<std::string> g_prof_names;
 std::vector<ProfRec> g_prof_recs;
 std::vector<hipEvent_t> g_prof_pool;
@@ -77,14 +80,16 @@ hipEvent_t prof_event() {
 }
 void prof_collect() {
   for (auto& r : g_prof_recs) {
-    (void)hipEventSynchronize(r.b);
-    float ms = 0.f;
-    (void)hipEventElapsedTime(&ms, r.a, r.b);
-    ProfAgg& a = g_prof_agg[g_prof_names[r.name]];
-    a.launches += 1;
-    a.ms += ms;
-    a.flops += r.flops;
-    a.bytes += r.bytes;
+    if (r.used) {
+      (void)hipEventSynchronize(r.b);
+      float ms = 0.f;
+      (void)hipEventElapsedTime(&ms, r.a, r.b);
+      ProfAgg& a = g_prof_agg[g_prof_names[r.name]];
+      a.launches += 1;
+      a.ms += ms;
+      a.flops += r.flops;
+      a.bytes += r.bytes;
+    }
     g_prof_pool.push_back(r.a);
     g_prof_pool.push_back(r.b);
   }
@@ -97,7 +102,7 @@ void prof_collect() {
 void tbn_prof_begin(const char* kernel, double flops, hipStream_t st, double bytes) {
   if (!g_prof_on) return;
   std::lock_guard<std::mutex> lk(g_prof_mu);
-  std::string key = kernel;
+  std::string key = g_prof_prefix ? std::string(g_prof_prefix) + kernel : std::string(kernel);
   if (g_prof_layers) key += " | " + g_prof_label;
   kernel = key.c_str();
   int idx = -1;
@@ -113,9 +118,20 @@ void tbn_prof_begin(const char* kernel, double flops, hipStream_t st, double byt
   r.bytes = bytes;
   r.a = prof_event();
   r.b = prof_event();
-  (void)hipEventRecord(r.a, st);
+  r.used = false;
+  (void)st;
   g_prof_recs.push_back(r);
   g_prof_open = (int)g_prof_recs.size() - 1;
+}
+bool tbn_prof_launch_events(hipEvent_t* start, hipEvent_t* stop) {
+  if (!g_prof_on) return false;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  if (g_prof_open < 0 || g_prof_recs[g_prof_open].used || !g_prof_recs[g_prof_open].a || !g_prof_recs[g_prof_open].b)
+    return false;
+  g_prof_recs[g_prof_open].used = true;
+  *start = g_prof_recs[g_prof_open].a;
+  *stop = g_prof_recs[g_prof_open].b;
+  return true;
 }
 void tbn_prof_label(const char* label) {
   if (!g_prof_on || !g_prof_layers) return;
@@ -125,7 +141,7 @@ void tbn_prof_label(const char* label) {
 void tbn_prof_end(hipStream_t st) {
   if (!g_prof_on) return;
   std::lock_guard<std::mutex> lk(g_prof_mu);
-  if (g_prof_open >= 0) (void)hipEventRecord(g_prof_recs[g_prof_open].b, st);
+  (void)st;
   g_prof_open = -1;
 }
 
@@ -383,14 +399,23 @@ int tbn_conv2d_wgrad(const float* dout, int dout_ld, const float* in, int in_ld,
 }
 
 // ---- linear = 1x1 conv over an (m,1,1,k) "image"
+namespace {
+struct ProfPrefix {   // profiler entries of the launches made inside the scope carry the prefix
+  explicit ProfPrefix(const char* p) { g_prof_prefix = p; }
+  ~ProfPrefix() { g_prof_prefix = nullptr; }
+};
+}  // namespace
+
 int tbn_linear_fwd(const float* x, int x_ld, const float* w, const float* bias, float* out, int out_ld, int m, int k,
                    int n, int relu, void* stream) {
+  ProfPrefix scope("linear: ");
   return tbn_conv2d_fwd(x, x_ld, w, bias, out, out_ld, m, 1, 1, k, n, 1, 1, 0, CONV_EPI_PLAIN,
                         relu ? CONV_FLAG_RELU : 0, nullptr, nullptr, nullptr, stream);
 }
 
 int tbn_linear_dgrad(const float* dy, int dy_ld, const float* w, float* dx, int dx_ld, int m, int k, int n,
                      int accumulate, float* workspace, void* stream) {
+  ProfPrefix scope("linear: ");
   return tbn_conv2d_dgrad(dy, dy_ld, w, dx, dx_ld, m, 1, 1, k, n, 1, 1, 0, accumulate, workspace, stream);
 }
 
@@ -398,6 +423,7 @@ size_t tbn_linear_wgrad_workspace_floats(int m, int k, int n) { return tbn_wgrad
 
 int tbn_linear_wgrad(const float* dy, int dy_ld, const float* x, int x_ld, float* dw, float* dbias, int m, int k,
                      int n, float* workspace, void* stream) {
+  ProfPrefix scope("linear: ");
   TBN_TRY(tbn_conv2d_wgrad(dy, dy_ld, x, x_ld, dw, m, 1, 1, k, n, 1, 1, 0, workspace, stream));
   if (dbias) TBN_TRY(tbn_colsum(dy, dy_ld, dbias, m, n, stream));
   return TBN_OK;

@@ -1366,9 +1366,9 @@ __global__ void weight_flip_transpose_kernel(const float* __restrict__ w, float*
 template <int MT, int NT, bool RM, int EPI, bool RED = false>
 static void launch_conv_e(const ConvP& p, hipStream_t st) {
   if (p.stages == 2)
-    hipLaunchKernelGGL((conv_igemm_kernel<MT, NT, RM, EPI, 2, RED>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, st, p);
+    TBN_LAUNCH((conv_igemm_kernel<MT, NT, RM, EPI, 2, RED>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, st, p);
   else
-    hipLaunchKernelGGL((conv_igemm_kernel<MT, NT, RM, EPI, 1, RED>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, st, p);
+    TBN_LAUNCH((conv_igemm_kernel<MT, NT, RM, EPI, 1, RED>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, st, p);
 }
 template <int MT, int NT, bool RM>
 static void launch_conv(const ConvP& p, hipStream_t st) {
@@ -1402,7 +1402,7 @@ static int launch_halo_e(const ConvP& p, size_t lds_bytes, hipStream_t st) {
     }
     allowed = 160 * 1024;
   }
-  hipLaunchKernelGGL((conv_halo_kernel<MT, NT, EPI, RED>), dim3(p.tiles_m * p.tiles_n), dim3(256), lds_bytes, st, p);
+  TBN_LAUNCH((conv_halo_kernel<MT, NT, EPI, RED>), dim3(p.tiles_m * p.tiles_n), dim3(256), lds_bytes, st, p);
   return TBN_OK;
 }
 template <int MT, int NT>
@@ -1417,26 +1417,26 @@ template <int MT, int NT>
 static void launch_sk4(const ConvP& p, hipStream_t st) {
   const dim3 grid(p.tiles_m * p.tiles_n);
   if (p.mode == CONV_EPI_STATS)
-    hipLaunchKernelGGL((conv_sk4_kernel<MT, NT, 1, false>), grid, dim3(256), 0, st, p);
+    TBN_LAUNCH((conv_sk4_kernel<MT, NT, 1, false>), grid, dim3(256), 0, st, p);
   else if (p.mode == CONV_EPI_EVAL)
-    hipLaunchKernelGGL((conv_sk4_kernel<MT, NT, 2, false>), grid, dim3(256), 0, st, p);
+    TBN_LAUNCH((conv_sk4_kernel<MT, NT, 2, false>), grid, dim3(256), 0, st, p);
   else if (p.nred > 0)
-    hipLaunchKernelGGL((conv_sk4_kernel<MT, NT, 0, true>), grid, dim3(256), 0, st, p);
+    TBN_LAUNCH((conv_sk4_kernel<MT, NT, 0, true>), grid, dim3(256), 0, st, p);
   else
-    hipLaunchKernelGGL((conv_sk4_kernel<MT, NT, 0, false>), grid, dim3(256), 0, st, p);
+    TBN_LAUNCH((conv_sk4_kernel<MT, NT, 0, false>), grid, dim3(256), 0, st, p);
 }
 
 template <int MT, int NT>
 static void launch_dma(const ConvP& p, hipStream_t st) {
   const dim3 grid(p.tiles_m * p.tiles_n);
   if (p.mode == CONV_EPI_STATS)
-    hipLaunchKernelGGL((conv_dma_kernel<MT, NT, 1, false>), grid, dim3(256), 0, st, p);
+    TBN_LAUNCH((conv_dma_kernel<MT, NT, 1, false>), grid, dim3(256), 0, st, p);
   else if (p.mode == CONV_EPI_EVAL)
-    hipLaunchKernelGGL((conv_dma_kernel<MT, NT, 2, false>), grid, dim3(256), 0, st, p);
+    TBN_LAUNCH((conv_dma_kernel<MT, NT, 2, false>), grid, dim3(256), 0, st, p);
   else if (p.nred > 0)
-    hipLaunchKernelGGL((conv_dma_kernel<MT, NT, 0, true>), grid, dim3(256), 0, st, p);
+    TBN_LAUNCH((conv_dma_kernel<MT, NT, 0, true>), grid, dim3(256), 0, st, p);
   else
-    hipLaunchKernelGGL((conv_dma_kernel<MT, NT, 0, false>), grid, dim3(256), 0, st, p);
+    TBN_LAUNCH((conv_dma_kernel<MT, NT, 0, false>), grid, dim3(256), 0, st, p);
 }
 
 void tbn_conv_pick_tile(int M, int Cout, int K, int* mt_out, int* nt_out) {
@@ -1748,7 +1748,7 @@ int tbn_launch_conv(ConvP p, int rowmode, int mt, int nt, hipStream_t st) {
     tbn_prof_begin(nm, flops_total, st, conv_alg_bytes(p, 0));
   }
 #define TBN_PLAUNCH(MTv, NTv, STv, REDv) \
-  hipLaunchKernelGGL((conv_igemm_phases_kernel<MTv, NTv, STv, REDv>), dim3(phases.blk0[phases.n]), dim3(256), 0, st, phases)
+  TBN_LAUNCH((conv_igemm_phases_kernel<MTv, NTv, STv, REDv>), dim3(phases.blk0[phases.n]), dim3(256), 0, st, phases)
 #define TBN_PCASE(MTv, NTv)                          \
   if (pmt == MTv && pnt == NTv) {                    \
     if (stages == 2) {                               \
@@ -1809,11 +1809,11 @@ static int launch_pair_v(const ConvPair& q, int blocks, int variant, size_t lds_
       }
       allowed = 160 * 1024;
     }
-    hipLaunchKernelGGL((conv_pair_halo_kernel<MT, NT, EPI, RED>), dim3(blocks), dim3(256), lds_bytes, st, q);
+    TBN_LAUNCH((conv_pair_halo_kernel<MT, NT, EPI, RED>), dim3(blocks), dim3(256), lds_bytes, st, q);
   } else if (variant == 2) {
-    hipLaunchKernelGGL((conv_pair_igemm_kernel<MT, NT, EPI, 2, RED>), dim3(blocks), dim3(256), 0, st, q);
+    TBN_LAUNCH((conv_pair_igemm_kernel<MT, NT, EPI, 2, RED>), dim3(blocks), dim3(256), 0, st, q);
   } else {
-    hipLaunchKernelGGL((conv_pair_igemm_kernel<MT, NT, EPI, 1, RED>), dim3(blocks), dim3(256), 0, st, q);
+    TBN_LAUNCH((conv_pair_igemm_kernel<MT, NT, EPI, 1, RED>), dim3(blocks), dim3(256), 0, st, q);
   }
   return TBN_OK;
 }
@@ -1876,7 +1876,7 @@ int tbn_launch_conv_pair(ConvP a, ConvP b, int variant, int mt, int nt, hipStrea
 
 template <int MT, int NT, int MODE>
 static void launch_wgrad(const WgradP& p, int blocks, hipStream_t st) {
-  hipLaunchKernelGGL((conv_wgrad_kernel<MT, NT, MODE>), dim3(blocks), dim3(256), 0, st, p);
+  TBN_LAUNCH((conv_wgrad_kernel<MT, NT, MODE>), dim3(blocks), dim3(256), 0, st, p);
 }
 
 // 32-column sub-tiles per workgroup along one dimension: 3 for 96 (and other odd multiples of 96), else 2 when the

@@ -1214,6 +1214,8 @@ int tbn_backbone_autotune(tbn_backbone_plan* P, int training, const tbn_backbone
         float ms = 0.f;
         (void)hipEventElapsedTime(&ms, ce[2 * k], ce[2 * k + 1]);
         if (any_halo && cand[k].halo != 1) ms *= 1.f + halo_bias;
+        // (a like margin AGAINST the single-stage register-staged loop -- more latency tolerance beside the other
+        //  streams -- measured worse: 36.06 -> 36.33 / 36.38 ms at 5 / 12 %)
         if (ms < best) {
           best = ms;
           bm = cand[k].mt;

@@ -1,6 +1,7 @@
 // Internal launch-level interface between the HIP kernels and the C-ABI / backbone engine.
 #pragma once
 #include "tbn_common.h"
+#include <hip/hip_ext.h>
 
 enum { CONV_EPI_PLAIN = 0, CONV_EPI_STATS = 1, CONV_EPI_EVAL = 2 };
 enum {
@@ -98,10 +99,22 @@ struct WgradP {
   int ablate;             // timing ablations, honoured by -DTBN_ABLATE=1 builds only (scripts/wgrad_ablate.py)
 };
 
-// optional in-process profiler: brackets every conv-GEMM launch with hipEvents on its stream
+// optional in-process profiler: every conv-GEMM launch gets a pair of hipEvents on its stream.  The events ride ON the
+// kernel's dispatch packet (hipExtLaunchKernelGGL: begin / end timestamps of the kernel itself, what rocprofv3's kernel
+// trace reports); rounds 1-2 recorded two separate marker packets around the launch, whose processing sat inside the
+// bracket (HIP-event averages 2.8 % above rocprofv3's for the same launches, round-2 verdict).
 void tbn_prof_begin(const char* kernel, double flops, hipStream_t st, double alg_bytes = 0.0);
 void tbn_prof_end(hipStream_t st);
 void tbn_prof_label(const char* label);
+bool tbn_prof_launch_events(hipEvent_t* start, hipEvent_t* stop);   // true: an open profiler record wants this launch timed
+#define TBN_LAUNCH(kernel, grid, block, lds, st, ...)                                            \
+  do {                                                                                           \
+    hipEvent_t tbn_e0__, tbn_e1__;                                                               \
+    if (tbn_prof_launch_events(&tbn_e0__, &tbn_e1__))                                            \
+      hipExtLaunchKernelGGL(kernel, grid, block, lds, st, tbn_e0__, tbn_e1__, 0, __VA_ARGS__);  \
+    else                                                                                         \
+      hipLaunchKernelGGL(kernel, grid, block, lds, st, __VA_ARGS__);                             \
+  } while (0)
 
 // conv_igemm.hip
 void tbn_conv_pick_tile(int M, int Cout, int K, int* mt, int* nt);
