@@ -35,6 +35,9 @@
 #ifndef TBN_ABLATE
 #define TBN_ABLATE 0
 #endif
+#ifndef TBN_DIAG
+#define TBN_DIAG 0   // timing-diagnostic build: see ConvP::fold_scale
+#endif
 #define ABL(bit) (TBN_ABLATE && (p.flags & (bit)))
 #define WABL(bit) (TBN_ABLATE && (p.ablate & (bit)))   // weight-gradient kernel: 1 no loop loads, 2 no LDS stores, 4 no MFMA
 
@@ -590,7 +593,22 @@ __device__ __forceinline__ void conv_halo_body(const ConvP& p, const int bid, fl
       ha[j] = buf_load4(in_rsrc, ok ? (unsigned)pix * (unsigned)p.in_ld * 4u + (unsigned)c4 * 16u : TBN_OOB, soff);
     }
   };
-  auto store_halo = [&]() {
+  auto store_halo = [&](int c0) {
+#if TBN_DIAG
+    if (p.fold_scale != nullptr) {   // cost probe: BN apply + ReLU of the producer layer at staging time (zero padding kept)
+      const float4 fs = *reinterpret_cast<const float4*>(p.fold_scale + c0 + c4 * 4);
+      const float4 fh = *reinterpret_cast<const float4*>(p.fold_shift + c0 + c4 * 4);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const bool ok = (r0 + 32 * j < HR) && ((unsigned)(pix0 + 32 * j) < (unsigned)p.M);
+        ha[j].x = ok ? fmaxf(fmaf(ha[j].x, fs.x, fh.x), 0.f) : 0.f;
+        ha[j].y = ok ? fmaxf(fmaf(ha[j].y, fs.y, fh.y), 0.f) : 0.f;
+        ha[j].z = ok ? fmaxf(fmaf(ha[j].z, fs.z, fh.z), 0.f) : 0.f;
+        ha[j].w = ok ? fmaxf(fmaf(ha[j].w, fs.w, fh.w), 0.f) : 0.f;
+      }
+    }
+#endif
+    (void)c0;
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
       if (r0 + 32 * j < HR) *reinterpret_cast<float4*>(&As[(r0 + 32 * j) * LDT + c4 * 4]) = ha[j];
@@ -622,7 +640,7 @@ __device__ __forceinline__ void conv_halo_body(const ConvP& p, const int bid, fl
   load_halo(0);
   load_b(0, 0);
   if (tid < LDT) As[HR * LDT + tid] = 0.f;
-  store_halo();
+  store_halo(0);
   store_b(Bs0);
   __syncthreads();
 
@@ -678,7 +696,7 @@ __device__ __forceinline__ void conv_halo_body(const ConvP& p, const int bid, fl
       __syncthreads();
     }
     if (next_chunk) {   // every wave is past its last read of this chunk's halo (barrier above)
-      store_halo();
+      store_halo((c + 1) * 32);
       __syncthreads();
     }
   }
@@ -1191,6 +1209,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
   const unsigned x_step = (unsigned)(4 * KR * p.x_ld) * 4u;
   const int tap_y = r - p.pad, tap_x = s - p.pad;
   const unsigned xld4 = (unsigned)p.x_ld * 4u;
+#if TBN_DIAG
+  bool x_ok_staged = false;   // validity of the x row in flight (cost probe below)
+#endif
   auto load_tiles = [&]() {
 #pragma unroll
     for (int k = 0; k < AI; ++k) ra[k] = buf_load4(dy_rsrc, dyo + 64u * k);
@@ -1208,6 +1229,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
         const bool ok = (iy < (unsigned)p.H) && (ix < (unsigned)p.W);
         const unsigned off = fb + __umul24(__umul24(iy, (unsigned)p.W) + ix, xld4);
         const unsigned voff = ok ? off : TBN_OOB;
+#if TBN_DIAG
+        x_ok_staged = ok;
+#endif
 #pragma unroll
         for (int k = 0; k < BI; ++k) rb[k] = buf_load4(x_rsrc, voff + 64u * k);
       } else {
@@ -1223,7 +1247,30 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
       fb += wrap ? p.fb_hi : p.fb_lo;
     }
   };
+#if TBN_DIAG
+  // cost probe (see ConvP::fold_scale): BN apply + ReLU of the producer layer on the staged x rows; out-of-image taps stay zero
+  float4 fsc[BI], fsh[BI];
+  if (MODE == 0 && p.fold_scale != nullptr) {
+#pragma unroll
+    for (int k = 0; k < BI; ++k) {
+      const int cc = min(ci0 + lq * 4 + 16 * k, p.Cin - 4);
+      fsc[k] = *reinterpret_cast<const float4*>(p.fold_scale + cc);
+      fsh[k] = *reinterpret_cast<const float4*>(p.fold_shift + cc);
+    }
+  }
+#endif
   auto store_tiles = [&]() {
+#if TBN_DIAG
+    if (MODE == 0 && p.fold_scale != nullptr) {
+#pragma unroll
+      for (int k = 0; k < BI; ++k) {
+        rb[k].x = x_ok_staged ? fmaxf(fmaf(rb[k].x, fsc[k].x, fsh[k].x), 0.f) : 0.f;
+        rb[k].y = x_ok_staged ? fmaxf(fmaf(rb[k].y, fsc[k].y, fsh[k].y), 0.f) : 0.f;
+        rb[k].z = x_ok_staged ? fmaxf(fmaf(rb[k].z, fsc[k].z, fsh[k].z), 0.f) : 0.f;
+        rb[k].w = x_ok_staged ? fmaxf(fmaf(rb[k].w, fsc[k].w, fsh[k].w), 0.f) : 0.f;
+      }
+    }
+#endif
 #pragma unroll
     for (int k = 0; k < AI; ++k) *reinterpret_cast<float4*>(&At[lrow16 * WA + lq * 4 + 16 * k]) = ra[k];
 #pragma unroll

@@ -146,6 +146,7 @@ struct tbn_backbone_plan {
   size_t weight_floats, chan_floats;
   // workspace layout (float offsets unless noted)
   size_t x0_off, stats_off, partial_off, coef_off, wsplit_off, wt_off, wpack_off, dwpack_off;
+  size_t diag_fold_off;   // -DTBN_DIAG=1 builds: ones | zeros (2 x 2048 floats) for the operand-staging cost probe (TBN_DIAG_FOLD=1)
   FlipTab flip;  // data-gradient weights: one flip/transpose launch per backward pass
   size_t partial_floats, wsplit_floats, wt_floats;
   size_t argmax_bytes_off, total_bytes_train, total_bytes_eval;
@@ -501,6 +502,17 @@ static inline bool diag_skip(int bit) {
   return false;
 #endif
 }
+// TBN_DIAG_FOLD=1 (diagnostic build only): the 3x3 / stride-1 layers apply an identity "BN apply + ReLU" (scale 1, shift 0)
+// to their input while staging it (LDS-halo forward / data gradient) and in the weight gradient's x operand -- the VALU cost
+// of folding the producer's BN apply into the consumers, with unchanged results (their inputs are post-ReLU already)
+static inline bool diag_fold() {
+#if TBN_DIAG
+  static const int on = getenv("TBN_DIAG_FOLD") ? atoi(getenv("TBN_DIAG_FOLD")) : 0;
+  return on != 0;
+#else
+  return false;
+#endif
+}
 void plan_memory(tbn_backbone_plan* P) {
   const size_t R = P->frames;
   size_t off = 0;
@@ -576,6 +588,7 @@ void plan_memory(tbn_backbone_plan* P) {
         c.parts[k].bpart_off = take(((size_t)cdiv(drows, drows <= kSk4MaxRows ? 32 : 128) + 4) * 2 * c.parts[k].cout);
       }
   P->coef_off = take(TBN_BN_MAXL * 3 * 1024);
+  P->diag_fold_off = take(2 * 2048);
   P->wsplit_off = take(wsplit);
   P->wt_off = take(wtf);
   P->dwpack_off = take((size_t)64 * P->stem_rows * P->kw);
@@ -792,6 +805,10 @@ void fill_fwd(const tbn_backbone_plan* P, const Conv& c, int training, float* ws
   }
   p.stages = c.ft[training ? 1 : 0].stages;
   p.halo = c.ft[training ? 1 : 0].halo;
+  if (diag_fold() && training && !c.stem && c.k == 3 && c.stride == 1) {
+    p.fold_scale = ws + P->diag_fold_off;
+    p.fold_shift = ws + P->diag_fold_off + 2048;
+  }
 }
 
 // data-gradient launch parameters of one GEMM: conv of dy with flipped / transposed weights (parity phases for
@@ -880,6 +897,10 @@ void fill_wgrad(const tbn_backbone_plan* P, const Conv& c, float* ws, int R, Wgr
     wp->Cin = c.cin;
     wp->R = wp->S = c.k;
     wp->taps = c.k * c.k;
+    if (diag_fold() && c.k == 3) {
+      wp->fold_scale = ws + P->diag_fold_off;
+      wp->fold_shift = ws + P->diag_fold_off + 2048;
+    }
   }
 }
 
@@ -916,6 +937,10 @@ int tbn_backbone_forward(const tbn_backbone_plan* P, int training, const float* 
   float* shift = scale + P->chan_floats;
   float* wpack = ws + P->wpack_off;
 
+  if (diag_fold() && training) {
+    (void)hipMemsetD32Async((hipDeviceptr_t)(ws + P->diag_fold_off), 0x3f800000, 2048, st);
+    (void)hipMemsetD32Async((hipDeviceptr_t)(ws + P->diag_fold_off + 2048), 0, 2048, st);
+  }
   if (P->stem_mode == 1) {
     TBN_TRY(tbn_launch_nchw_to_nhwc_pad(x_nchw, ws + P->x0_off, R, P->cin0, P->H, P->W, P->stem_H, P->stem_W, st));
     TBN_TRY(tbn_launch_pack_stem_weight_rows(prm->weight + P->convs[0].w_off, wpack, 64, P->cin0, P->kw, P->stem_K, st));
@@ -1309,6 +1334,8 @@ int tbn_backbone_autotune(tbn_backbone_plan* P, int training, const tbn_backbone
         }
       }
       const float singles = pass == 0 ? c.ft[tr].t + c2.ft[tr].t : c.t_dgrad + c2.t_dgrad;
+      // (margins of 0.88 / 1.05 instead of 0.97 measured 0.1-0.15 ms worse on the three-stream step; moving the weight flip
+      //  to the tail of the forward, under the other streams, +-0: 36.81 vs 36.75 ms)
       const bool take = rc == TBN_OK && best < 0.97f * singles;
       if (pass == 0) {
         c.ft[tr].pair = take;

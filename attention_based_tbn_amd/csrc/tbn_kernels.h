@@ -71,6 +71,11 @@ struct ConvP {
   int ty0, tny, tx0, tnx;               // the taps form a grid: tap (ry, rx) = (ty0 + ry, tx0 + rx), t = ry*tnx + rx
   FastDiv div_ohw, div_ow;              // m -> (n, a, b) without integer division
   FastDiv div_rl4;                      // ROWMODE: float4 index inside K -> (run, float4 inside the run)
+  // -DTBN_DIAG=1 builds only (scripts/README.md, TBN_DIAG_FOLD): per-input-channel scale / shift applied with a ReLU when
+  // the LDS-halo kernel stages its patch -- the COST side of folding the producer's BN apply into this conv's operand
+  // staging (the engine passes ones / zeros: results unchanged); null = off, never read by the shipped build
+  const float* fold_scale;
+  const float* fold_shift;
 };
 
 struct WgradP {
@@ -96,6 +101,8 @@ struct WgradP {
   unsigned row_step, col_step;   // ROWMODE: bytes per output row / column step in the padded image (stride folded in)
   double alg_flops;       // host only
   unsigned dy_bytes, x_bytes;   // exact extents (last row ends at its last column): lanes beyond them read zeros
+  const float* fold_scale;      // -DTBN_DIAG=1 builds only: as ConvP::fold_scale, applied to the staged x operand
+  const float* fold_shift;
   int ablate;             // timing ablations, honoured by -DTBN_ABLATE=1 builds only (scripts/wgrad_ablate.py)
 };
 
