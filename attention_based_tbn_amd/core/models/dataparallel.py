@@ -18,6 +18,12 @@ module lists in `maybe_unused_parameter_prefixes()` -- the audio backbone and th
 those gradients while another does not -- are reduced at the end of backward in registration order, zero-filled
 where absent, together with one presence flag each; a parameter no rank produced a gradient for gets `grad = None`
 back, which is what the reference's optimiser sees when every nn.DataParallel replica dropped the audio feature.
+The drop decision is a HOST draw made during forward: when the module also reports it (`optional_parameters_used()`),
+the ranks exchange it right after forward -- a 1-element all-reduce on a side stream, read back through a pinned buffer
+and an event, never through the compute stream -- so that every rank knows BEFORE backward whether all, some or none of
+the replicas kept the branch: all -> the optional tensors are reduced from their gradient hooks like any other (the
+~41 MB audio backbone overlaps the other backbones' backward instead of being exposed at the end), none -> they are
+skipped and come back as `grad = None` without any end-of-step host read, some -> the zero-filled end-of-backward path.
 
 `DataParallel(model)` keeps the reference surface: `.module`, `forward`, `get_loss(...)`,
 `state_dict()` of the wrapped model under the `module.` prefix.
@@ -42,6 +48,10 @@ class DataParallel(nn.Module):
         self._fired = set()             # ids of the parameters whose gradient hook ran in this backward
         self._callback_queued = False
         self._hooks = []
+        self._sync = True               # False inside no_sync(): gradients stay local (accumulation steps, tests)
+        self._presence = None           # ("pending", event, pinned host tensor) | ("count", n): see _exchange_presence
+        self._side_stream = None
+        self._host_flag = None
         self.world_size = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
         if self.world_size > 1:
             if broadcast_parameters:
@@ -78,6 +88,54 @@ class DataParallel(nn.Module):
             return set()
         return {id(p) for n, p in self.module.named_parameters() if p.requires_grad and n.startswith(prefixes)}
 
+    def no_sync(self):
+        """context manager: backward passes inside it leave the gradients un-reduced (as torch DDP's `no_sync`)"""
+        import contextlib
+
+        @contextlib.contextmanager
+        def ctx():
+            old, self._sync = self._sync, False
+            try:
+                yield
+            finally:
+                self._sync = old
+        return ctx()
+
+    def _exchange_presence(self):
+        """after a training forward: how many replicas used the optional parameters in this step (the module's
+        host-side draw).  Issued on a side stream so that neither the collective nor the read-back waits for the
+        forward kernels queued on the compute stream."""
+        self._presence = None
+        fn = getattr(self.module, "optional_parameters_used", None)
+        if fn is None or not self._optional_ids():
+            return
+        used = 1.0 if fn() else 0.0
+        dev = next(self.module.parameters()).device
+        if dev.type == "cuda":
+            if self._side_stream is None:
+                self._side_stream = torch.cuda.Stream(device=dev)
+                self._host_flag = torch.zeros(1, dtype=torch.float32).pin_memory()
+            with torch.cuda.stream(self._side_stream):
+                t = torch.tensor([used], dtype=torch.float32).pin_memory().to(dev, non_blocking=True)
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.process_group, async_op=True).wait()
+                self._host_flag.copy_(t, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(self._side_stream)
+            self._presence = ("pending", ev, t)      # `t` kept alive until the copy has run
+        else:
+            t = torch.tensor([used])
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.process_group)
+            self._presence = ("count", int(round(float(t.item()))))
+
+    def _presence_count(self):
+        """number of replicas that used the optional parameters in this step, or None when the module does not report it"""
+        if self._presence is None:
+            return None
+        if self._presence[0] == "pending":
+            self._presence[1].synchronize()          # the side stream's copy: microseconds, not the step's kernels
+            self._presence = ("count", int(round(float(self._host_flag.item()))))
+        return self._presence[1]
+
     def _on_grad_ready(self, p):
         """post-accumulate-grad hook.  A large (flat backbone) gradient is all-reduced right here: the hook
         runs inside the AccumulateGrad node, whose stream the autograd engine has already made wait for the
@@ -87,9 +145,14 @@ class DataParallel(nn.Module):
         same (reverse-forward) order on every rank and only for parameters every rank produces (optional ones
         wait for the end), so the collectives match up.  Small tensors are only remembered; one callback at
         the end of backward packs and reduces them and waits for everything."""
+        if not self._sync:
+            return
         if not self._callback_queued:
             self._callback_queued = True
             self._optional = self._optional_ids()
+            self._count = self._presence_count() if self._optional else None
+            if self._count == self.world_size:
+                self._optional = set()       # every replica produced them: ordinary, hook-overlapped reduction
             torch.autograd.Variable._execution_engine.queue_callback(self.finish_gradient_sync)
         self._fired.add(id(p))
         if self.overlap and p.grad is not None and p.grad.numel() >= self.SMALL and id(p) not in self._optional:
@@ -106,13 +169,15 @@ class DataParallel(nn.Module):
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
         optional = getattr(self, "_optional", set())
+        count = getattr(self, "_count", None)
+        nobody = count == 0                  # known before backward: no replica used the optional parameters
         in_flight = {id(p) for p, _ in self._pending}
         params = [p for p in self.module.parameters() if p.requires_grad]      # registration order: rank independent
         present = {}
         for p in params:
             if id(p) in optional:
                 present[id(p)] = p.grad is not None and id(p) in self._fired
-                if not present[id(p)]:
+                if not present[id(p)] and not nobody:
                     p.grad = torch.zeros_like(p)         # this rank dropped it: contributes zeros, same schedule
         # a non-optional parameter without a gradient is skipped -- on every rank alike (same contract as torch DDP
         # with find_unused_parameters=False); small ones still travel (as zeros) so that the packed size is fixed
@@ -144,9 +209,12 @@ class DataParallel(nn.Module):
                     p.grad.copy_(flat[off:off + p.numel()].view_as(p))
                 off += p.numel()
             if opt_list:
-                # one host read per step, only while the module declares optional parameters (audio dropout)
-                anyone = flat[off:off + len(opt_list)].cpu() > 0
-                for p, a in zip(opt_list, anyone.tolist()):
+                if count is None:
+                    # the module does not report its draw: one host read per step tells which tensors nobody produced
+                    anyone = (flat[off:off + len(opt_list)].cpu() > 0).tolist()
+                else:
+                    anyone = [not nobody] * len(opt_list)      # exchanged after forward: no end-of-step host read
+                for p, a in zip(opt_list, anyone):
                     if not a:
                         p.grad = None                      # no replica produced it: the optimiser skips it
         if ev0 is not None:
@@ -155,6 +223,8 @@ class DataParallel(nn.Module):
         self._pending = []
         self._fired = set()
         self._callback_queued = False
+        self._presence = None
+        self._count = None
 
     def exposed_sync_ms(self):
         """mean GPU time the compute stream spent inside finish_gradient_sync (the all-reduce tail that backward did
@@ -166,7 +236,10 @@ class DataParallel(nn.Module):
         return sum(ms) / len(ms)
 
     def forward(self, *args, **kwargs):
-        return self.module(*args, **kwargs)
+        out = self.module(*args, **kwargs)
+        if self.world_size > 1 and self._sync and self.module.training and torch.is_grad_enabled():
+            self._exchange_presence()
+        return out
 
     def get_loss(self, criterion, target, preds, epoch=0):
         return self.module.get_loss(criterion, target, preds, epoch)

@@ -133,6 +133,11 @@ class TBNModel(nn.Module):
             return ["Base_Audio.", "pe.", "attention_layer."]
         return []
 
+    def optional_parameters_used(self):
+        """whether the last forward kept the audio feature (the host draw of reference model.py:219): lets `DataParallel`
+        exchange the decision right after forward instead of discovering it at the end of backward"""
+        return not self._audio_dropped
+
     def _aggregate_scores(self, scores, new_shape=(1, -1)):
         assert isinstance(scores, (dict, torch.Tensor))
         assert isinstance(new_shape, tuple)
@@ -172,6 +177,7 @@ class TBNModel(nn.Module):
         features = []
         att_wts = None
         att = self.cfg.model.attention
+        self._audio_dropped = False
         raw_all = self._run_backbones(input)
         for m_no, m in enumerate(self.modality):
             b, n, c, h, w = input[m].shape
@@ -182,6 +188,7 @@ class TBNModel(nn.Module):
                 if (self.training and len(self.modality) > 1 and self.cfg.data.audio.dropout > 0
                         and np.random.uniform() > self.cfg.data.audio.dropout):
                     feature = torch.zeros_like(features[0])
+                    self._audio_dropped = True
                 elif self.use_attention:
                     seq = raw                                           # (R, T, 1024)
                     if att.use_fixed:

@@ -42,7 +42,8 @@ def run(m):
     torch.cuda.synchronize()
     model.module.load_state_dict(st)                      # undo the BN running-stat update
     return {k: p.grad.clone() for k, p in model.module.named_parameters() if p.grad is not None}
-local = run(model.module)                                 # no collective
+with model.no_sync():
+    local = run(model.module)                             # gradient hooks off: this rank's own gradients
 synced = run(model)                                       # hooks: backbone all-reduces inside backward, small tensors at its end
 for k, gl in local.items():
     parts = [torch.empty_like(gl) for _ in range(2)]
@@ -51,6 +52,46 @@ for k, gl in local.items():
     err = float((synced[k] - want).abs().max() / (want.abs().max() + 1e-20))
     assert err < 1e-5, (k, err)
 assert len(local) >= 12 and model._fired == set() and model._pending == []
+
+# ---- audio dropout (reference model.py:215-222: a per-replica host draw): the ranks exchange the draw after forward on
+# a side stream; all kept / one dropped / both dropped must give the mean of the local gradients (zeros where dropped),
+# and `None` for the audio branch when nobody kept it
+import numpy as np
+cfg2 = load_config(["data.flow.enable=False", "data.audio.audio_length=1.279", "model.fusion_dropout=0",
+                    "model.attention.enable=False", "data.audio.dropout=0.5"])
+torch.manual_seed(3)
+model2, crit2, _ = build_model(cfg2, get_modality(cfg2), dev)
+model2.train()
+assert model2.module.maybe_unused_parameter_prefixes()
+def seed_for(drop):                                      # a NumPy seed whose first uniform() is > 0.5 (drop) or not
+    s = 0
+    while (np.random.RandomState(s).uniform() > 0.5) != drop: s += 1
+    return s
+def run2(m, drop):
+    for p in m.parameters(): p.grad = None
+    st = {k: v.clone() for k, v in model2.module.state_dict().items()}
+    np.random.seed(seed_for(drop))
+    out = m(inp); loss, _ = m.get_loss(crit2, tgt, out, 12); loss["total"].backward()
+    torch.cuda.synchronize()
+    model2.module.load_state_dict(st)
+    return {k: (p.grad.clone() if p.grad is not None else None) for k, p in model2.module.named_parameters() if p.requires_grad}
+named2 = dict(model2.module.named_parameters())
+for drops in ((False, False), (False, True), (True, True), (True, False)):
+    with model2.no_sync():
+        local2 = run2(model2.module, drops[rank])
+    synced2 = run2(model2, drops[rank])
+    assert model2._presence is None and model2._pending == []
+    for k, gs in synced2.items():
+        gl = local2[k] if local2[k] is not None else torch.zeros_like(named2[k])
+        parts = [torch.empty_like(gl) for _ in range(2)]
+        dist.all_gather(parts, gl)
+        if k.startswith("Base_Audio.") and all(drops):
+            assert gs is None, (drops, k)                 # nobody kept the branch: the optimiser must see None
+            continue
+        want = (parts[0] + parts[1]) / 2
+        assert gs is not None, (drops, k)
+        err = float((gs - want).abs().max() / (want.abs().max() + 1e-20))
+        assert err < 1e-5, (drops, k, err)
 print("DP_GPU_OK", rank, len(local))
 '''
 
@@ -69,7 +110,7 @@ def test_dataparallel_real_model_two_ranks_on_one_gpu(tmp_path):
                                       stderr=subprocess.STDOUT, text=True))
     outs = [p.communicate(timeout=600)[0] for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):
-        assert p.returncode == 0 and f"DP_GPU_OK {r}" in o, o[-3000:]
+        assert p.returncode == 0 and f"DP_GPU_OK {r}" in o, "\n".join(f"---- rank {i}: {x[-2500:]}" for i, x in enumerate(outs))
 
 
 def test_bench_n2_control_flow_rehearsal():

@@ -162,6 +162,8 @@ class Toy(nn.Module):
         self.register_buffer("count", torch.full((2,), rank, dtype=torch.long))
         self.drop = False
     def maybe_unused_parameter_prefixes(self): return ["c."] if case != "avg" else []
+    if os.environ.get("DP_REPORT", "1") == "1":     # the module reports its draw: exchanged right after forward
+        def optional_parameters_used(self): return not self.drop
     def forward(self, x):
         u = torch.zeros(x.shape[0], 4) if self.drop else self.c(x)
         return self.b(torch.relu(self.a(x)) + u)
@@ -193,19 +195,30 @@ for it, drops in enumerate(steps):
         else:
             assert p.grad is not None and torch.allclose(p.grad, q.grad, atol=1e-6), (it, n)
     assert model._pending == [] and model._fired == set() and not model._callback_queued and bs == 4
+with model.no_sync():                               # gradients stay local: rank-dependent data -> rank-dependent gradients
+    model.zero_grad(set_to_none=True); model.module.drop = False
+    nn.MSELoss()(model(xs), ys).backward()
+    mine = model.module.a.weight.grad.clone()
+both = [torch.empty_like(mine) for _ in range(2)]
+dist.all_gather(both, mine)
+assert not torch.allclose(both[0], both[1]) and model._pending == [] and not model._callback_queued
 sd = model.state_dict(); assert all(k.startswith("module.") for k in sd)
 print("DP_OK", rank)
 '''
 
 
 @pytest.mark.parametrize("overlap,case", [(True, "avg"), (False, "avg"), (True, "drop1"), (False, "drop1"),
-                                          (True, "dropall"), (True, "flip"), (False, "flip")])
+                                          (True, "dropall"), (True, "flip"), (False, "flip"), (True, "flip-noreport"),
+                                          (True, "drop1-noreport")])
 def test_dataparallel_gradient_average_gloo_world2(tmp_path, overlap, case):
     """2 gloo ranks: gradients equal the full-batch ones; with an optional branch (the audio-dropout rule, reference
     model.py:215-222, drawn per replica) dropped on ONE rank the collective schedule still matches and the result is
     the full-batch gradient; dropped on every rank its gradients come back as None; "flip" runs five CONSECUTIVE steps
     whose drop decision changes every step (one rank, both, the other, none, both): the wrapper's per-step state
-    (presence flags, pending collectives, fired hooks, the queued callback) must reset between them"""
+    (presence flags, pending collectives, fired hooks, the queued callback, the exchanged draw) must reset between them.
+    By default the module reports its draw (`optional_parameters_used`) and the ranks exchange it after forward (all /
+    none / some replicas -> hook-overlapped / skipped / zero-filled reduction); "-noreport" runs the fallback in which the
+    wrapper only learns it from the presence flags at the end of backward"""
     script = tmp_path / "dp_worker.py"
     script.write_text(_DP_WORKER)
     with socket.socket() as s:
@@ -214,7 +227,8 @@ def test_dataparallel_gradient_average_gloo_world2(tmp_path, overlap, case):
     procs = []
     for r in range(2):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   OMP_NUM_THREADS="1", DP_OVERLAP=str(int(overlap)), DP_CASE=case)
+                   OMP_NUM_THREADS="1", DP_OVERLAP=str(int(overlap)), DP_CASE=case.replace("-noreport", ""),
+                   DP_REPORT="0" if case.endswith("-noreport") else "1")
         procs.append(subprocess.Popen([sys.executable, str(script), ROOT], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.STDOUT, text=True))
     outs = [p.communicate(timeout=240)[0] for p in procs]
