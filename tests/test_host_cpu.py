@@ -301,3 +301,42 @@ def test_c_abi_rejects_bad_arguments_before_touching_the_gpu():
     # conv: K not a multiple of 32 (cin = 10, 3x3)
     fails(L.tbn_conv2d_fwd(bad, 10, bad, bad, bad, 64, 2, 8, 8, 10, 64, 3, 1, 1, 0, 0, None, None, None, None),
           "multiples of 32")
+    # descriptor entry points (round 3): host-side validation of every form they can express
+    from attention_based_tbn_amd._lib import ConvDesc
+
+    def desc(**kw):
+        d = ConvDesc()
+        d.inp, d.in_ld, d.weight, d.out, d.out_ld = bad, 32, bad, bad, 32
+        d.n, d.h, d.w, d.cin, d.cout, d.ksize, d.stride, d.pad = 1, 8, 8, 32, 32, 3, 1, 1
+        for k, v in kw.items():
+            setattr(d, k, v)
+        return d
+    fails(L.tbn_conv_launch(C.byref(desc(epilogue=1)), 1, 1, None, None), "stat_partial")
+    fails(L.tbn_conv_launch(C.byref(desc(epilogue=2)), 1, 1, None, None), "scale/shift")
+    fails(L.tbn_conv_launch(C.byref(desc(nred=1)), 1, 1, None, None), "belongs to a data gradient")
+    fails(L.tbn_conv_launch(C.byref(desc(dgrad=1)), 1, 1, None, None), "flipped-weight workspace")
+    fails(L.tbn_conv_launch(C.byref(desc(inp=0)), 1, 1, None, None), "null pointer")
+    # partial rows: 128-row tiles (32 for the split-K tile variant), per parity phase for a strided data gradient
+    assert L.tbn_conv_partial_rows(C.byref(desc(n=3, h=14, w=14)), 1, 0) == 5
+    assert L.tbn_conv_partial_rows(C.byref(desc(n=3, h=14, w=14, flags=16)), 1, 0) == 19
+    assert L.tbn_conv_partial_rows(C.byref(desc(n=3, h=14, w=14, flags=16)), 1, 1) == 5      # a pair uses 128-row tiles
+    assert L.tbn_conv_partial_rows(C.byref(desc(n=2, h=15, w=15, stride=2, dgrad=1)), 1, 0) == 4   # 8x8, 8x7, 7x8, 7x7 phases
+
+
+def test_launch_info_reports_the_plan_choices_per_mode():
+    """tbn_backbone_launch_info on a fresh plan (host only): size-heuristic tiles for both modes, no data-gradient
+    entries in eval mode or for the stem, an error for an unknown layer"""
+    import ctypes as C
+    from attention_based_tbn_amd._lib import lib
+    L = lib()
+    h = C.c_void_p()
+    assert L.tbn_backbone_plan_create(3, 4, 96, 96, C.byref(h)) == 0
+    buf = (C.c_int * 16)()
+    for training in (0, 1):
+        assert L.tbn_backbone_launch_info(h, b"inception_4a_3x3", training, buf) == 0
+        v = list(buf)
+        assert v[0] == 0 and v[1] in (1, 2) and 1 <= v[2] <= 4 and v[4] == 0          # untuned: generic kernel, no pairing
+        assert (v[8:] == [0] * 8) == (training == 0) or v[9] >= 1
+    assert L.tbn_backbone_launch_info(h, b"conv1_7x7_s2", 1, buf) == 0 and list(buf)[8:] == [0] * 8   # the stem has no data gradient
+    assert L.tbn_backbone_launch_info(h, b"no_such_layer", 1, buf) < 0 and b"unknown conv" in L.tbn_last_error()
+    L.tbn_backbone_plan_destroy(h)
