@@ -136,6 +136,11 @@ def lib():
             raise TbnHipError(
                 f"{LIB_PATH} not found: build it with `python -m attention_based_tbn_amd.build` "
                 "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the TBN hot path.")
+        # torch first: its wheel bundles its own HIP runtime (libamdhip64, SONAME .so.7 like the system's); whichever copy
+        # is loaded first serves the whole process.  Loading libtbn_hip.so before torch pulled in /opt/rocm's runtime, and
+        # the first kernel launch then failed with "no ROCm-capable device is detected" (the two disagree on the device
+        # set-up torch does) -- seen when __graft_entry__.build() and smoke() ran in one process.
+        import torch  # noqa: F401
         handle = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)   # AttributeError if a declared symbol is not exported
