@@ -164,7 +164,10 @@ class TBNModel(nn.Module):
         for m in self.modality:
             st = self._streams.get(m)
             if st is None or st.device != first.device:
-                st = self._streams[m] = torch.cuda.Stream(device=first.device)
+                # the heaviest backbone (audio: 5.1 GFLOP per 256x256 frame against 4.1 / 4.6) gets the high-priority
+                # stream: it is the one that finishes last and runs alone at the end of forward and backward (same-box
+                # A/B, 3 of 3: 36.13 -> 35.92 ms per step; issuing it first instead: +-0)
+                st = self._streams[m] = torch.cuda.Stream(device=first.device, priority=(-1 if m == "Audio" else 0))
             st.wait_stream(main)
             with torch.cuda.stream(st):
                 raw[m] = run(m)
