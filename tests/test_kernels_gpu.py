@@ -552,6 +552,19 @@ def test_stft_logpower_vs_oracle(L):
         assert np.abs(spec[i] - ref).max() < 2e-3      # log-power domain, fp32 DFT vs fp64 FFT
 
 
+def test_stft_logpower_many_segments_match_single_launches():
+    """config-4 volume in one launch (96 waveforms -> 768 workgroups): every segment is bit-identical to the same waveform
+    launched alone, and the zero padding of one segment never reads its neighbours' samples"""
+    from attention_based_tbn_amd.core.dataset import Spectrogram
+    L = 30695
+    wave = (0.1 * torch.randn(96, L, generator=g(11))).to(DEV)
+    spec = Spectrogram()
+    full = spec(wave)
+    assert full.shape == (96, 256, 256) and torch.isfinite(full).all()
+    for i in (0, 1, 47, 95):
+        assert torch.equal(full[i], spec(wave[i:i + 1].contiguous())[0]), i
+
+
 def test_log_mel_spectrogram_vs_oracle():
     """spec_type='logms': STFT kernel + mel GEMM + max-referenced dB, against the NumPy oracle"""
     from oracle.stft import log_mel_spectrogram
