@@ -647,12 +647,18 @@ __device__ __forceinline__ void conv_halo_body(const ConvP& p, const int bid, fl
   const int nchunks = p.Cin >> 5;
   const char* As_b = reinterpret_cast<const char*>(As);
   int ks = 0;
-  for (int c = 0; c < nchunks; ++c) {
-    const bool next_chunk = c + 1 < nchunks;
-    if (next_chunk) load_halo((c + 1) * 32);   // nine K-steps to land
+  // One 32-channel chunk = nine taps.  NEXT (a type, so every `if` on it is resolved at compile time): there is another
+  // chunk behind this one -- its halo is fetched at the top and the B tile of its tap 0 during tap 8.  The last chunk is a
+  // second copy of the body WITHOUT those parts rather than the same code under `if (c + 1 < nchunks)`: with the prefetches
+  // under a run-time condition the compiler's wait-count pass must assume that the B-tile loads of the previous trip may
+  // still be in flight where the first ds_read of a trip reuses their registers, and put `s_waitcnt vmcnt(1)` there --
+  // right behind the thirteen halo loads just issued, i.e. every chunk started by waiting for its successor's halo.
+  auto chunk = [&](const int c, auto next_tag) {
+    constexpr bool NEXT = decltype(next_tag)::value;
+    if (NEXT) load_halo((c + 1) * 32);   // lands during tap 0 (the first B-tile wait is behind it in vmcnt order)
 #pragma unroll
     for (int t = 0; t < 9; ++t, ++ks) {
-      const bool more = next_chunk || t < 8;
+      const bool more = NEXT || t < 8;
       if (more) load_b(t < 8 ? t + 1 : 0, t < 8 ? c * 32 : (c + 1) * 32);
       const float* Bs = Bs0 + (ks & 1) * (BN * LDT);
       float4 fa[2][MT], fb[2][NT];
@@ -684,6 +690,9 @@ __device__ __forceinline__ void conv_halo_body(const ConvP& p, const int bid, fl
       mfma_group(1);
       {
         constexpr int NR = MT + NT, NM = 4 * MT * NT;
+        // (the B-tile loads of the next tap are left to the scheduler, which sinks them to 4-12 MFMAs in front of the
+        // ds_write that waits for them: pinning them to the top of the tap with a VMEM group measured 0-2 % SLOWER on
+        // warm clocks, 25 % on one <1,3> shape -- the weights are L2 hits and the early loads lengthen live ranges)
         __builtin_amdgcn_sched_group_barrier(0x100, 2 * NR, 0);
         __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
         __builtin_amdgcn_sched_group_barrier(0x100, NR, 0);
@@ -695,11 +704,13 @@ __device__ __forceinline__ void conv_halo_body(const ConvP& p, const int bid, fl
       if (more) store_b(Bs0 + ((ks + 1) & 1) * (BN * LDT));
       __syncthreads();
     }
-    if (next_chunk) {   // every wave is past its last read of this chunk's halo (barrier above)
+    if (NEXT) {   // every wave is past its last read of this chunk's halo (barrier above)
       store_halo((c + 1) * 32);
       __syncthreads();
     }
-  }
+  };
+  for (int c = 0; c + 1 < nchunks; ++c) chunk(c, std::true_type{});
+  chunk(nchunks - 1, std::false_type{});
   conv_epilogue<MT, NT, EPI, RED>(p, acc, lds, tm, m0, n0);
 }
 
