@@ -340,3 +340,30 @@ def test_launch_info_reports_the_plan_choices_per_mode():
     assert L.tbn_backbone_launch_info(h, b"conv1_7x7_s2", 1, buf) == 0 and list(buf)[8:] == [0] * 8   # the stem has no data gradient
     assert L.tbn_backbone_launch_info(h, b"no_such_layer", 1, buf) < 0 and b"unknown conv" in L.tbn_last_error()
     L.tbn_backbone_plan_destroy(h)
+
+
+def test_isa_wait_scan_flags_a_wait_right_behind_its_load(tmp_path, capsys):
+    """scripts/isa_wait_scan.py on a synthetic listing: a loop that waits vmcnt(0) two MFMAs behind a load is reported as
+    tight, the same loop with the load issued a whole trip earlier (vmcnt(1)) is not"""
+    import runpy, sys
+    def listing(wait):
+        body = ["_Z4demov:", ".LBB0_1:", "\tbuffer_load_dwordx4 v[0:3], v9, s[0:3], 0 offen"]
+        body += ["\tv_mfma_f32_32x32x2_f32 v[16:31], v4, v5, v[16:31]"] * 2
+        body += ["\t" + wait, "\tds_write_b128 v8, v[0:3]"]
+        body += ["\tv_mfma_f32_32x32x2_f32 v[16:31], v4, v5, v[16:31]"] * 14
+        body += ["\ts_cbranch_scc1 .LBB0_1", "\ts_endpgm"]
+        return "\n".join(body) + "\n"
+    script = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "isa_wait_scan.py")
+    out = []
+    for name, wait in (("tight.s", "s_waitcnt vmcnt(0)"), ("far.s", "s_waitcnt vmcnt(1)")):
+        f = tmp_path / name
+        f.write_text(listing(wait))
+        old = sys.argv
+        sys.argv = [script, str(f), "demo"]
+        try:
+            runpy.run_path(script, run_name="__main__")
+        finally:
+            sys.argv = old
+        out.append(capsys.readouterr().out)
+    assert "tightest wait   2 MFMAs" in out[0] and "1 of 1 waits closer than 12" in out[0], out[0]
+    assert "tightest wait  18 MFMAs" in out[1] and "0 of 1 waits closer than 12" in out[1], out[1]
