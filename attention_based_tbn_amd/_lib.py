@@ -55,6 +55,7 @@ SIGNATURES = {
     "tbn_profile_entry": (c_i, [c_i, C.c_char_p, c_i, C.POINTER(C.c_long), C.POINTER(C.c_double),
                                 C.POINTER(C.c_double)]),
     "tbn_profile_entry_bytes": (c_i, [c_i, C.POINTER(C.c_double)]),
+    "tbn_diag_mfma_burst": (c_i, [c_fp, c_i, c_i, C.POINTER(C.c_double), c_fp]),
     "tbn_backbone_plan_create": (c_i, [c_i, c_i, c_i, c_i, C.POINTER(C.c_void_p)]),
     "tbn_backbone_plan_destroy": (None, [C.c_void_p]),
     "tbn_backbone_num_convs": (c_i, [C.c_void_p]),

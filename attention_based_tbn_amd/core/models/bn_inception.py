@@ -143,7 +143,11 @@ class _BackboneFn(torch.autograd.Function):
         prm = BackboneParams(ptr(weight), ptr(bias), ptr(gamma), ptr(beta), ptr(module.running_mean),
                              ptr(module.running_var), 0.1, 1e-5)
         aux = 0
-        if module.use_aux_stream:
+        # inside a stream capture (torch.cuda.graph of a whole step) the weight gradients stay on the launch stream: the
+        # engine refuses an aux stream there (TBN_ERR_UNSUPPORTED -- a capture that forks from an already forked stream
+        # overflows the stack of ROCm 7.x's hipStreamEndCapture, and whether this stream is the capture's origin cannot be
+        # queried), so a captured step degrades to serial weight-gradient launches instead of raising from autograd
+        if module.use_aux_stream and not torch.cuda.is_current_stream_capturing():
             cur = torch.cuda.current_stream()
             a = module._aux_streams.get(cur.cuda_stream)
             if a is None:

@@ -36,7 +36,11 @@ import torch.nn as nn
 class DataParallel(nn.Module):
     SMALL = 1 << 18   # elements: gradients below 1 MB travel together in one flat buffer (one collective)
 
-    def __init__(self, module, device_ids=None, process_group=None, broadcast_parameters=True, overlap=True):
+    def __init__(self, module, device_ids=None, process_group=None, broadcast_parameters=True, overlap=True,
+                 force_sync=False):
+        """`force_sync`: register the gradient hooks and run every collective even when the group has ONE rank (the
+        default wraps a lone rank as a pass-through) -- puts the real hook -> all_reduce(async_op) -> queue_callback ->
+        work.wait() path under RCCL's stream semantics on a single GPU (tests/test_dp_gpu.py)."""
         super().__init__()
         self.module = module
         self.device_ids = device_ids
@@ -52,8 +56,12 @@ class DataParallel(nn.Module):
         self._presence = None           # ("pending", event, pinned host tensor) | ("count", n): see _exchange_presence
         self._side_stream = None
         self._host_flag = None
+        self._forwards_pending = 0      # training forwards since the last synchronised backward (see forward())
         self.world_size = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
-        if self.world_size > 1:
+        if force_sync and not (dist.is_available() and dist.is_initialized()):
+            raise RuntimeError("DataParallel(force_sync=True) needs an initialised process group")
+        self.active = self.world_size > 1 or force_sync
+        if self.active:
             if broadcast_parameters:
                 self.broadcast_parameters()
             for p in self.module.parameters():
@@ -150,6 +158,7 @@ class DataParallel(nn.Module):
         if not self._callback_queued:
             self._callback_queued = True
             self._optional = self._optional_ids()
+            self._optional_all = set(self._optional)
             self._count = self._presence_count() if self._optional else None
             if self._count == self.world_size:
                 self._optional = set()       # every replica produced them: ordinary, hook-overlapped reduction
@@ -171,6 +180,18 @@ class DataParallel(nn.Module):
         optional = getattr(self, "_optional", set())
         count = getattr(self, "_count", None)
         nobody = count == 0                  # known before backward: no replica used the optional parameters
+        if count is not None:
+            # the exchanged draw must describe THIS backward: a rank whose optional parameters fired although "nobody"
+            # kept them (or did not although "all" did) would issue a different collective schedule than its peers and
+            # hang the job inside RCCL -- fail here, loudly, instead
+            produced = [id(p) in self._fired and p.grad is not None
+                        for p in self.module.parameters() if id(p) in getattr(self, "_optional_all", set())]
+            if (count == 0 and any(produced)) or (count == self.world_size and not all(produced)):
+                self._pending, self._fired, self._callback_queued, self._presence, self._count = [], set(), False, None, None
+                self._forwards_pending = 0
+                raise RuntimeError("DataParallel: the optional-parameter draw exchanged after forward (%d of %d replicas) "
+                                   "does not match the gradients this backward produced; one forward per backward is "
+                                   "assumed when the module reports its draw" % (count, self.world_size))
         in_flight = {id(p) for p, _ in self._pending}
         params = [p for p in self.module.parameters() if p.requires_grad]      # registration order: rank independent
         present = {}
@@ -225,6 +246,7 @@ class DataParallel(nn.Module):
         self._callback_queued = False
         self._presence = None
         self._count = None
+        self._forwards_pending = 0
 
     def exposed_sync_ms(self):
         """mean GPU time the compute stream spent inside finish_gradient_sync (the all-reduce tail that backward did
@@ -237,8 +259,17 @@ class DataParallel(nn.Module):
 
     def forward(self, *args, **kwargs):
         out = self.module(*args, **kwargs)
-        if self.world_size > 1 and self._sync and self.module.training and torch.is_grad_enabled():
-            self._exchange_presence()
+        if self.active and self._sync and self.module.training and torch.is_grad_enabled():
+            # the module's draw is per forward, the exchange describes ONE forward: when a second training forward
+            # arrives before the backward of the first (two forwards feeding one backward, or a forward whose loss was
+            # never back-propagated), the count no longer says which gradients the coming backward produces -> drop it
+            # and let that backward take the presence-flag path (rank-independent schedule, one host read at its end).
+            # Every rank runs the same number of forwards, so they all take the same branch.
+            if self._forwards_pending == 0:
+                self._exchange_presence()
+            else:
+                self._presence = None
+            self._forwards_pending += 1
         return out
 
     def get_loss(self, criterion, target, preds, epoch=0):

@@ -145,9 +145,41 @@ void tbn_prof_end(hipStream_t st) {
   g_prof_open = -1;
 }
 
+// Box calibration (bench.py `box.mfma_calibration`): a pure v_mfma_f32_32x32x2_f32 loop, operands in registers, no memory
+// traffic -- what THIS device sustains on the instruction the roofline is priced in (157.3 TFLOP/s nominal; boxes of one
+// pool differ by a few per cent in the clock they hold).  Four rotating accumulators: a dependent MFMA is only free right
+// behind its producer or >= 4 MFMAs later (hardware finding 2).
+__global__ __launch_bounds__(256) void mfma_burst_kernel(float* sink, int iters) {
+  f32x16 a0, a1, a2, a3;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) a0[e] = a1[e] = a2[e] = a3[e] = 0.f;
+  const float x = 1e-3f * (float)(threadIdx.x & 63) + 0.5f, y = 1.0f - 1e-3f * (float)(threadIdx.x >> 6);
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, a0, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(y, x, a1, 0, 0, 0);
+      a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, x, a2, 0, 0, 0);
+      a3 = __builtin_amdgcn_mfma_f32_32x32x2f32(y, y, a3, 0, 0, 0);
+    }
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) s += (a0[e] + a1[e]) + (a2[e] + a3[e]);
+  if (s == -1.2345f) sink[0] = s;   // never true (all terms are positive): keeps the loop alive without a store
+}
+
 extern "C" {
 
-int tbn_version(void) { return 100; }
+int tbn_version(void) { return 101; }
+
+int tbn_diag_mfma_burst(float* sink, int workgroups, int iters, double* flops, void* stream) {
+  TBN_REQUIRE(sink != nullptr && workgroups > 0 && workgroups <= 65536 && iters > 0, "diag_mfma_burst: bad argument");
+  hipLaunchKernelGGL(mfma_burst_kernel, dim3(workgroups), dim3(256), 0, (hipStream_t)stream, sink, iters);
+  TBN_CHECK_LAUNCH("mfma_burst");
+  if (flops) *flops = (double)workgroups * 4.0 * (double)iters * 16.0 * 4096.0;   // 2 * 32 * 32 * 2 per MFMA
+  return TBN_OK;
+}
 
 int tbn_profile_enable(int on) {
   std::lock_guard<std::mutex> lk(g_prof_mu);

@@ -1725,6 +1725,17 @@ int tbn_launch_conv(ConvP p, int rowmode, int mt, int nt, hipStream_t st) {
   TBN_REQUIRE(!rowmode && p.stride == 1 && p.R == p.S && p.R * p.S <= 9, "conv: unsupported strided data gradient");
   const double flops_total = p.alg_flops;
   const int full_M = p.N * p.OH * p.OW;
+  {
+    // the scatter epilogue forms its byte offsets as 24-bit products (output pixel) x (row pitch in bytes): v_mul_u32_u24
+    // silently drops the high bits, so both factors are checked here (the 2-GiB extent checks alone do not imply it
+    // for narrow pitches)
+    bool pitches_ok = true;
+    for (int i = 0; i < p.nseg; ++i) pitches_ok = pitches_ok && (size_t)p.seg[i].ld * 4 < (1u << 24);
+    for (int i = 0; i < p.nred; ++i) pitches_ok = pitches_ok && (size_t)p.red[i].y_ld * 4 < (1u << 24);
+    TBN_REQUIRE(full_M < (1 << 24) && pitches_ok,
+                "conv: strided data gradient of %d output pixels / a pitch beyond the 24-bit scatter arithmetic (chunk the frames)",
+                full_M);
+  }
   static thread_local ConvPhases phases;   // ~2 KB kernel argument, built in place
   phases.n = 0;
   bool empty_phase = false;
@@ -2120,7 +2131,7 @@ __global__ __launch_bounds__(256) void weight_flip_transpose_all_kernel(const fl
                                                                         float* __restrict__ wt, FlipTab tab) {
   // all taps of the tile are loaded first (up to 36 loads in flight per thread), ONE barrier, then all are written:
   // the former tap-by-tap form (two barriers per 4-KB tap slice) ran the 40 MB of a backbone at ~1 TB/s
-  __shared__ float tile[9][32][33];
+  __shared__ float tile[9][32][33];   // indexed by tap < tab.taps[l] <= 9 (checked by the launcher)
   int lo = 0, hi = tab.n;
   while (hi - lo > 1) {
     const int mid = (lo + hi) >> 1;
@@ -2154,6 +2165,8 @@ __global__ __launch_bounds__(256) void weight_flip_transpose_all_kernel(const fl
 
 int tbn_launch_weight_flip_transpose_all(const float* w, float* wt, const FlipTab& tab, hipStream_t st) {
   if (tab.n == 0) return TBN_OK;
+  for (int l = 0; l < tab.n; ++l)   // the kernel stages every tap of a tile at once: tile[9][32][33]
+    TBN_REQUIRE(tab.taps[l] >= 1 && tab.taps[l] <= 9, "weight_flip: layer %d has %d taps (at most 9 = 3x3)", l, (int)tab.taps[l]);
   hipLaunchKernelGGL(weight_flip_transpose_all_kernel, dim3(tab.blk0[tab.n]), dim3(256), 0, st, w, wt, tab);
   TBN_CHECK_LAUNCH("weight_flip_transpose_all");
   return TBN_OK;

@@ -1235,14 +1235,17 @@ int tbn_backbone_autotune(tbn_backbone_plan* P, int training, const tbn_backbone
       static const float halo_bias = getenv("TBN_TUNE_HALO_BIAS") ? 0.01f * (float)atof(getenv("TBN_TUNE_HALO_BIAS")) : 0.08f;
       bool any_halo = false;
       for (int k = 0; k < ncand; ++k) any_halo = any_halo || cand[k].halo == 1;
+      float best_raw = 1e30f;   // the winner's MEASURED time: the traffic margin only ranks candidates, it is not a time
       for (int k = 0; k < ncand && rc == TBN_OK; ++k) {
         float ms = 0.f;
         (void)hipEventElapsedTime(&ms, ce[2 * k], ce[2 * k + 1]);
+        const float raw = ms;
         if (any_halo && cand[k].halo != 1) ms *= 1.f + halo_bias;
         // (a like margin AGAINST the single-stage register-staged loop -- more latency tolerance beside the other
         //  streams -- measured worse: 36.06 -> 36.33 / 36.38 ms at 5 / 12 %)
         if (ms < best) {
           best = ms;
+          best_raw = raw;
           bm = cand[k].mt;
           bn = cand[k].nt;
           bs = cand[k].stages;
@@ -1255,13 +1258,13 @@ int tbn_backbone_autotune(tbn_backbone_plan* P, int training, const tbn_backbone
         T.nt = bn;
         T.stages = bs;
         T.halo = bh;
-        T.t = best;
+        T.t = best_raw;
       } else {
         c.d_mt = bm;
         c.d_nt = bn;
         c.d_stages = bs;
         c.d_halo = bh;
-        c.t_dgrad = best;
+        c.t_dgrad = best_raw;
       }
     }
     if (rc != TBN_OK) break;
@@ -1322,12 +1325,15 @@ int tbn_backbone_autotune(tbn_backbone_plan* P, int training, const tbn_backbone
       static const float pair_halo_bias = getenv("TBN_TUNE_HALO_BIAS") ? 0.01f * (float)atof(getenv("TBN_TUNE_HALO_BIAS")) : 0.08f;
       bool any_halo = false;   // cand[k].stages holds the pair variant: 0 = LDS-halo members (see the margin above)
       for (int k = 0; k < ncand; ++k) any_halo = any_halo || cand[k].stages == 0;
+      float best_raw = 1e30f;
       for (int k = 0; k < ncand && rc == TBN_OK; ++k) {
         float ms = 0.f;
         (void)hipEventElapsedTime(&ms, ce[2 * k], ce[2 * k + 1]);
+        const float raw = ms;
         if (any_halo && cand[k].stages != 0) ms *= 1.f + pair_halo_bias;
         if (ms < best) {
           best = ms;
+          best_raw = raw;
           bm = cand[k].mt;
           bn = cand[k].nt;
           bv = cand[k].stages;
@@ -1336,7 +1342,7 @@ int tbn_backbone_autotune(tbn_backbone_plan* P, int training, const tbn_backbone
       const float singles = pass == 0 ? c.ft[tr].t + c2.ft[tr].t : c.t_dgrad + c2.t_dgrad;
       // (margins of 0.88 / 1.05 instead of 0.97 measured 0.1-0.15 ms worse on the three-stream step; moving the weight flip
       //  to the tail of the forward, under the other streams, +-0: 36.81 vs 36.75 ms)
-      const bool take = rc == TBN_OK && best < 0.97f * singles;
+      const bool take = rc == TBN_OK && best_raw < 0.97f * singles;   // measured pair time against the measured singles
       if (pass == 0) {
         c.ft[tr].pair = take;
         c.ft[tr].p_variant = bv;

@@ -104,40 +104,235 @@ def pmc_traffic(kernel):
         return None
 
 
-def cpu_baseline(seconds_budget=25.0):
-    """the CPU oracle (torch-CPU restatement of the reference path) on this box's host cores:
-    same config-4 graph and full-size inputs, B=2 clips x 3 segments, fwd+loss+bwd"""
+def _median(v):
+    v = sorted(v)
+    return v[len(v) // 2] if len(v) % 2 else 0.5 * (v[len(v) // 2 - 1] + v[len(v) // 2])
+
+
+def roofline_object(samples, steps_in_first_sample, end_to_end_frac):
+    """`roofline` of the JSON line from the per-step profiler collections (instrumented single-stream steps run after the
+    timed loop): the dominant kernel = the conv-GEMM instantiation with the largest summed time; `achieved` / `frac` and
+    the conv-stage figure `all_conv_gemm` are MEDIANS over the samples, min / max beside them."""
+    samples = [sm for sm in samples if sm]
+    if not samples:
+        return None
+    conv = [[e for e in sm if not e["kernel"].startswith("linear: ")] for sm in samples]
+    heads = [[e for e in sm if e["kernel"].startswith("linear: ")] for sm in samples]
+    tot = {}
+    for sm in conv:
+        for e in sm:
+            t = tot.setdefault(e["kernel"], {"kernel": e["kernel"], "launches": 0, "ms": 0.0, "flops": 0.0, "alg_bytes": 0.0})
+            for k in ("launches", "ms", "flops", "alg_bytes"):
+                t[k] += e[k]
+    ranked = sorted(tot.values(), key=lambda e: -e["ms"])
+    top = ranked[0]
+    tf = lambda e: e["flops"] / (e["ms"] * 1e-3) / 1e12
+    top_tf = [tf(e) for sm in conv for e in sm if e["kernel"] == top["kernel"]]
+    top_us = [1e3 * e["ms"] / e["launches"] for sm in conv for e in sm if e["kernel"] == top["kernel"]]
+    all_tf = [sum(e["flops"] for e in sm) / (sum(e["ms"] for e in sm) * 1e-3) / 1e12 for sm in conv]
+    all_ms = [sum(e["ms"] for e in sm) for sm in conv]
+    all_ms[0] /= steps_in_first_sample
+    ach = _median(top_tf)
+    tr = pmc_traffic(top["kernel"])
+    tr_detail = tr
+    if tr and tr.get("stale"):
+        tr = None                      # stale counters: traffic is null, the detail says why
+    alg_b = top["alg_bytes"] / max(1, top["launches"])
+    fam = {}
+    for e in conv[-1]:                 # launches per kernel family in ONE profiled step: which variants the per-layer
+        f_ = e["kernel"].split("<")[0]  # autotuner actually put on this shape
+        fam[f_] = fam.get(f_, 0) + e["launches"] // (steps_in_first_sample if len(conv) == 1 else 1)
+    P = PEAK_FP32_MFMA_TFLOPS
+    nstep_total = steps_in_first_sample if len(conv) == 1 else len(conv)     # profiled steps behind the totals
+    return {"bound": "mfma", "achieved": round(ach, 2), "peak": P, "unit": "TFLOP/s", "frac": round(ach / P, 4),
+            "frac_min": round(min(top_tf) / P, 4), "frac_max": round(max(top_tf) / P, 4), "samples": len(conv),
+            "sampled": "instrumented single-stream steps AFTER the timed loop, one sample per step"
+                       if steps_in_first_sample == 1 or len(conv) > 1 else
+                       f"{steps_in_first_sample} instrumented steps INSIDE the timed loop (--profile-every), aggregated",
+            "traffic": (tr or {}).get("hbm_bytes_per_launch"),
+            "alg_bytes_per_launch": round(alg_b),
+            "traffic_ratio": round(tr["hbm_bytes_per_launch"] / alg_b, 3) if tr and alg_b > 0 else None,
+            "traffic_detail": tr_detail,
+            "kernel_families": fam,
+            "kernel": top["kernel"], "launches": top["launches"] // nstep_total,
+            "avg_launch_us": round(_median(top_us), 2),
+            "alg_gflop_per_launch": round(top["flops"] / top["launches"] / 1e9, 4),
+            "all_conv_gemm": {"achieved": round(_median(all_tf), 2), "frac": round(_median(all_tf) / P, 4),
+                              "frac_min": round(min(all_tf) / P, 4), "frac_max": round(max(all_tf) / P, 4),
+                              "ms_per_profiled_step": round(_median(all_ms), 2)},
+            "head_linear_gemm": {"launches": sum(e["launches"] for e in heads[-1]) // (steps_in_first_sample if len(conv) == 1 else 1),
+                                 "ms_per_profiled_step": round(sum(e["ms"] for e in heads[-1]) /
+                                                               (steps_in_first_sample if len(conv) == 1 else 1), 3)},
+            "end_to_end_frac": round(end_to_end_frac, 4),
+            "by_kernel": [{"kernel": e["kernel"], "launches": e["launches"] // nstep_total, "avg_us": round(1e3 * e["ms"] / e["launches"], 2),
+                           "tflops": round(tf(e), 2)} for e in ranked[:8]]}
+
+
+def host_cpu():
+    """CPU model string, physical cores and hardware threads of this box (from /proc/cpuinfo)"""
+    model, cores, threads = None, set(), 0
+    try:
+        phys = core = None
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                k, _, v = ln.partition(":")
+                k, v = k.strip(), v.strip()
+                if k == "model name" and model is None:
+                    model = v
+                elif k == "processor":
+                    threads += 1
+                elif k == "physical id":
+                    phys = v
+                elif k == "core id":
+                    core = v
+                elif not k and phys is not None and core is not None:
+                    cores.add((phys, core))
+                    phys = core = None
+        if phys is not None and core is not None:
+            cores.add((phys, core))
+    except OSError:
+        pass
+    return {"cpu_model": model, "physical_cores": len(cores) or None, "hardware_threads": threads or os.cpu_count(),
+            "usable_threads": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()}
+
+
+def box_identity(device):
+    """What this line was measured ON, so that two lines from two boxes of a pool explain their own gap: CPU model, GPU
+    name, rocm-smi's power cap / clocks when the tool answers, and a warm pure-fp32-MFMA burst (tbn_diag_mfma_burst:
+    registers only, no memory traffic) timed after 30 ms of the same load -- a cold burst runs ~12 % slow (DESIGN.md finding
+    13) -- as TFLOP/s and as a fraction of the 157.3 the roofline is priced in."""
+    import subprocess
+    from attention_based_tbn_amd._lib import call, ptr, stream_ptr
+    out = dict(host_cpu())
+    out["gpu_name"] = torch.cuda.get_device_name(device)
+    props = torch.cuda.get_device_properties(device)
+    out["gpu_cus"] = props.multi_processor_count
+    out["gpu_arch"] = getattr(props, "gcnArchName", None)
+    try:
+        r = subprocess.run(["rocm-smi", "--showpower", "--showmaxpower", "--showclocks", "--showperflevel", "--json"],
+                           capture_output=True, text=True, timeout=15)
+        doc = json.loads(r.stdout) if r.returncode == 0 and r.stdout.strip().startswith("{") else None
+        if doc:
+            card = doc.get("card%d" % device.index) or next(iter(doc.values()))
+            keep = {}
+            for k, v in card.items():
+                kl = k.lower()
+                if any(t in kl for t in ("power", "sclk", "mclk", "performance level")):
+                    keep[k] = v
+            out["rocm_smi"] = keep
+        else:
+            out["rocm_smi"] = None
+    except (OSError, ValueError, subprocess.SubprocessError, StopIteration):
+        out["rocm_smi"] = None
+    sink = torch.zeros(16, device=device)
+    fl = C.c_double()
+    wg, iters = 1024, 1500                                     # ~2.6 ms per launch at the nominal peak
+    for _ in range(14):                                        # ~35 ms of load: the clock is where it stays under a step
+        call("tbn_diag_mfma_burst", ptr(sink), wg, iters, C.byref(fl), stream_ptr())
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    reps = 8
+    for _ in range(reps):
+        call("tbn_diag_mfma_burst", ptr(sink), wg, iters, C.byref(fl), stream_ptr())
+    e1.record()
+    torch.cuda.synchronize()
+    tf = reps * fl.value / (e0.elapsed_time(e1) * 1e-3) / 1e12
+    out["mfma_calibration"] = {"tflops": round(tf, 1), "frac_of_peak": round(tf / PEAK_FP32_MFMA_TFLOPS, 4),
+                               "what": "v_mfma_f32_32x32x2_f32 register loop, 1024 workgroups x 4 waves, warm (after 35 ms "
+                                       "of the same load), 8 launches of ~2.6 ms"}
+    return out
+
+
+def _time_cpu(fn, warmup, min_steps, budget_s):
+    """`warmup` untimed calls, then at least `min_steps` timed ones (more while the budget lasts, at most 3x)"""
+    for _ in range(warmup):
+        fn()
+    t0 = time.perf_counter()
+    n = 0
+    while n < min_steps or (time.perf_counter() - t0 < budget_s and n < 3 * min_steps):
+        fn()
+        n += 1
+    return n, time.perf_counter() - t0
+
+
+def cpu_baseline():
+    """the CPU oracle (torch-CPU fp32 restatement of the reference path, oneDNN) on this box's host
+    cores, torch threads = physical cores, the same kind of seeded synthetic tensors as the GPU run, 2 warm-up + >= 5 timed
+    iterations per leg:
+      value        config-4 graph (RGB+Flow+Audio, attention off) at B = 4 clips x 3 segments, fwd + loss + bwd
+      other[...]   the same graph forward only; config 1 exactly (Audio-only, (4,1,1,256,256)) fwd and fwd+bwd; the config-5
+                   graph (RGB+Flow+Audio sync, MHA) at B = 1 clip x 25 segments, eval forward
+    The oracle is the checker of this repo, timed here as the baseline -- never part of the product path."""
     from attention_based_tbn_amd.config import load_config, get_modality
     from oracle.fill import pretrained_pair
     from oracle.tbn import build_model as build_oracle
-    cfg = load_config(["model.attention.enable=False", "data.audio.audio_length=1.279", "data.sampling=async"])
-    modality = get_modality(cfg)
-    torch.manual_seed(0)
-    model, crit, _ = build_oracle(cfg, modality, pretrained_pair(7))
-    model.train()
-    B, n = 2, 3
-    g = torch.Generator().manual_seed(0)
-    inp = {"RGB": torch.rand(B, n, 3, 224, 224, generator=g) - 0.45,
-           "Flow": torch.rand(B, n, 10, 224, 224, generator=g) - 0.5,
-           "Audio": torch.randn(B, n, 1, 256, 256, generator=g) * 3 - 6}
-    tgt = {"class": {"verb": torch.randint(0, 125, (B,), generator=g), "noun": torch.randint(0, 352, (B,), generator=g)}}
+    cpu = host_cpu()
+    old_threads = torch.get_num_threads()
+    cores = min(cpu["physical_cores"] or old_threads, cpu["usable_threads"] or old_threads)
+    torch.set_num_threads(max(1, cores))
 
-    def step():
-        model.zero_grad()
-        out = model(inp)
-        loss, _ = model.get_loss(crit, tgt, out, 0)
-        loss["total"].backward()
+    def make(ov, B, n, audio_w=256):
+        cfg = load_config(ov)
+        modality = get_modality(cfg)
+        torch.manual_seed(0)
+        model, crit, _ = build_oracle(cfg, modality, pretrained_pair(7))
+        g = torch.Generator().manual_seed(0)
+        inp = {}
+        if "RGB" in modality:
+            inp["RGB"] = torch.rand(B, n, 3, 224, 224, generator=g) - 0.45
+        if "Flow" in modality:
+            inp["Flow"] = torch.rand(B, n, 10, 224, 224, generator=g) - 0.5
+        if "Audio" in modality:
+            inp["Audio"] = (torch.randn(B, n, 1, 256, audio_w, generator=g) * 3 - 6).clamp_(-13.8155, 8.0)
+        tgt = {"class": {"verb": torch.randint(0, 125, (B,), generator=g), "noun": torch.randint(0, 352, (B,), generator=g)}}
+        return model, crit, inp, tgt
 
-    step()  # warm-up
-    t0 = time.perf_counter()
-    steps = 0
-    while steps < 2 or (time.perf_counter() - t0 < seconds_budget and steps < 8):
-        step()
-        steps += 1
-    dt = time.perf_counter() - t0
-    return {"value": B * steps / dt, "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{steps} fwd+bwd steps of the config-4 graph at B={B} clips x {n} segments, full-size "
-                      f"synthetic inputs, oracle/ (torch-CPU fp32, oneDNN) on the GPU box's host cores"}
+    def train_step(model, crit, inp, tgt):
+        def f():
+            model.zero_grad()
+            out = model(inp)
+            loss, _ = model.get_loss(crit, tgt, out, 0)
+            loss["total"].backward()
+        return f
+
+    def fwd_only(model, inp):
+        def f():
+            with torch.no_grad():
+                model(inp)
+        return f
+
+    legs = {}
+    try:
+        ov4 = ["model.attention.enable=False", "data.audio.audio_length=1.279", "data.sampling=async"]
+        model, crit, inp, tgt = make(ov4, 4, 3)
+        model.train()
+        n, dt = _time_cpu(train_step(model, crit, inp, tgt), 2, 5, 20.0)
+        head = {"value": 4 * n / dt, "steps": n}
+        n, dt = _time_cpu(fwd_only(model, inp), 2, 5, 6.0)
+        legs["config4_graph_B4_n3_train_mode_forward_only"] = {"clips_per_s": round(4 * n / dt, 3), "steps": n}
+        del model
+        ov1 = ["data.rgb.enable=False", "data.flow.enable=False", "model.attention.enable=False",
+               "data.audio.audio_length=1.279", "train.num_segments=1"]
+        model, crit, inp, tgt = make(ov1, 4, 1)
+        model.train()
+        n, dt = _time_cpu(train_step(model, crit, inp, tgt), 2, 5, 4.0)
+        legs["config1_audio_only_B4_n1_fwd_bwd"] = {"clips_per_s": round(4 * n / dt, 3), "steps": n}
+        n, dt = _time_cpu(fwd_only(model, inp), 2, 5, 3.0)
+        legs["config1_audio_only_B4_n1_fwd"] = {"clips_per_s": round(4 * n / dt, 3), "steps": n}
+        del model
+        model, crit, inp, tgt = make(["data.audio.audio_length=1.279"], 1, 25)
+        model.eval()
+        n, dt = _time_cpu(fwd_only(model, inp), 2, 5, 10.0)
+        legs["config5_graph_B1_n25_eval_fwd"] = {"clips_per_s": round(1 * n / dt, 3), "steps": n}
+        del model
+    finally:
+        torch.set_num_threads(old_threads)
+    return {"value": round(head["value"], 4), "unit": "clips/s", "cores": cores, "kind": "port",
+            "cpu_model": cpu["cpu_model"], "physical_cores": cpu["physical_cores"], "hardware_threads": cpu["hardware_threads"],
+            "sample": f"{head['steps']} timed fwd+loss+bwd steps (2 warm-ups) of the config-4 graph at B=4 clips x 3 segments, "
+                      f"full-size seeded synthetic inputs, oracle/ (torch-CPU fp32, oneDNN), torch threads = {cores} "
+                      "(physical cores usable by this process) on the GPU box's host",
+            "other": legs}
 
 
 def main():
@@ -164,9 +359,13 @@ def main():
     ap.add_argument("--stft-inputs", action="store_true",
                     help="the audio leg starts from WAVEFORMS (B, n, 30695 samples = 1.279 s at 24 kHz, resident in HBM): the "
                          "log-power STFT kernel (reference dataset.py:483-495, CPU librosa there) runs inside the timed step")
-    ap.add_argument("--profile-every", type=int, default=1 << 30,
-                    help="bracket conv-GEMM launches with HIP events on every k-th timed step (default: the first "
-                         "timed step only; 0 = never).  Profiled steps run single-stream, see DESIGN.md")
+    ap.add_argument("--profile-steps", type=int, default=3,
+                    help="instrumented single-stream steps run AFTER the timed loop (kernel timestamps on every conv-GEMM "
+                         "launch): `roofline` reports the median / min / max over them.  The timed region is the product "
+                         "step only")
+    ap.add_argument("--profile-every", type=int, default=0,
+                    help="diagnostic (rocprofv3 / PMC passes): ALSO instrument every k-th step INSIDE the timed loop, so a "
+                         "short traced run contains instrumented steps; the line then says timed_region_instrumented")
     ap.add_argument("--trace-streams", action="store_true",
                     help="diagnostic: after the timed loop run 3 more steps with HIP events around every backbone "
                          "forward / backward call and print (stderr) when each ran on the GPU and how long the host took "
@@ -304,6 +503,7 @@ def main():
         step()
     L = lib()
     L.tbn_profile_reset()
+    box = box_identity(device) if rank == 0 else None     # CPU / GPU names + a warm pure-MFMA burst: before the timed loop
     probe = None
     if world > 1:
         # one-shot all-reduce probe on a tensor the size of a backbone's flat weight gradient (the largest collective of a
@@ -331,24 +531,46 @@ def main():
     fence()
     if world > 1 and hasattr(model, "exposed_sync_ms"):
         model.exposed_sync_ms()     # drop the warm-up records
+    def profiled_step():
+        # kernel timestamps on every conv-GEMM launch; the backbones run on ONE stream (and the weight gradients on it
+        # too) so a bracket times exactly one kernel -- in the product step they overlap
+        core.multi_stream = False
+        for b_ in bases:
+            b_.use_aux_stream = False
+        L.tbn_profile_enable(1)
+        out = step()
+        L.tbn_profile_enable(0)
+        core.multi_stream = multi
+        for b_, a_ in zip(bases, aux):
+            b_.use_aux_stream = a_
+        return out
+
     t0 = time.perf_counter()
     for i in range(args.steps):
-        prof = args.profile_every > 0 and (i % args.profile_every == 0)
-        if prof:
-            # HIP-event brackets around every conv-GEMM launch; on these steps the three backbones run
-            # on ONE stream so a bracket times exactly one kernel (on the other steps they overlap)
-            core.multi_stream = False
-            for b_ in bases:
-                b_.use_aux_stream = False
-            L.tbn_profile_enable(1)
-        loss = step()
-        if prof:
-            L.tbn_profile_enable(0)
-            core.multi_stream = multi
-            for b_, a_ in zip(bases, aux):
-                b_.use_aux_stream = a_
+        if args.profile_every > 0 and (i % args.profile_every == 0):
+            loss = profiled_step()      # diagnostic runs only (see --profile-every): the default timed region has none
+        else:
+            loss = step()
     fence()
     dt = time.perf_counter() - t0
+    exposed_ms = None
+    if world > 1 and hasattr(model, "exposed_sync_ms"):
+        e = model.exposed_sync_ms()
+        t = torch.tensor([e if e is not None else 0.0], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        exposed_ms = float(t.item())
+    # instrumented steps AFTER the timed region (every rank runs them: the step holds collectives for N > 1); each one is
+    # collected on its own so that the conv-stage figure is a median over samples, not one step
+    prof_samples = []
+    if args.profile_every > 0:
+        prof_samples.append(collect_profile() if rank == 0 else [])
+    for _ in range(max(0, args.profile_steps) if args.profile_every <= 0 else 0):
+        L.tbn_profile_reset()
+        profiled_step()
+        torch.cuda.synchronize()
+        prof_samples.append(collect_profile() if rank == 0 else [])
+    if world > 1:
+        fence()
     rank_ms = None
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
@@ -376,54 +598,11 @@ def main():
                 print("  %-22s host %6.2f -> %6.2f ms (%.2f)   GPU %6.2f -> %6.2f ms (%.2f)" %
                       (name[4:], (t0 - h0) * 1e3, (t1 - h0) * 1e3, (t1 - t0) * 1e3, ref.elapsed_time(e0),
                        ref.elapsed_time(e1), e0.elapsed_time(e1)), file=sys.stderr)
-    exposed_ms = None
-    if world > 1 and hasattr(model, "exposed_sync_ms"):
-        e = model.exposed_sync_ms()
-        t = torch.tensor([e if e is not None else 0.0], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        exposed_ms = float(t.item())
-
     if rank == 0:
         clips = B * world * args.steps
         value = clips / dt
-        prof_all = sorted(collect_profile(), key=lambda e: -e["ms"])
-        # the BN-Inception conv stage (what the north star's roofline target is about) vs the head Linear GEMMs
-        # (fusion / classifier / attention projections: M = 32 ... 96 rows, < 0.2 % of the FLOPs, latency-bound)
-        prof = [e for e in prof_all if not e["kernel"].startswith("linear: ")]
-        heads = [e for e in prof_all if e["kernel"].startswith("linear: ")]
-        roofline = None
-        if prof:
-            top = prof[0]
-            ach = top["flops"] / (top["ms"] * 1e-3) / 1e12
-            tot_ms, tot_fl = sum(e["ms"] for e in prof), sum(e["flops"] for e in prof)
-            tr = pmc_traffic(top["kernel"])
-            tr_detail = tr
-            if tr and tr.get("stale"):
-                tr = None                      # stale counters: traffic is null, the detail says why
-            alg_b = top["alg_bytes"] / max(1, top["launches"])
-            fam = {}
-            for e in prof:                     # launches per kernel family in the profiled step(s): which variants the
-                f_ = e["kernel"].split("<")[0]  # per-layer autotuner actually put on this shape
-                fam[f_] = fam.get(f_, 0) + e["launches"]
-            roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": (tr or {}).get("hbm_bytes_per_launch"),
-                        "alg_bytes_per_launch": round(alg_b),
-                        "traffic_ratio": round(tr["hbm_bytes_per_launch"] / alg_b, 3) if tr and alg_b > 0 else None,
-                        "traffic_detail": tr_detail,
-                        "kernel_families": fam,
-                        "kernel": top["kernel"], "launches": top["launches"],
-                        "avg_launch_us": round(1e3 * top["ms"] / top["launches"], 2),
-                        "alg_gflop_per_launch": round(top["flops"] / top["launches"] / 1e9, 4),
-                        "all_conv_gemm": {"achieved": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2),
-                                          "frac": round(tot_fl / (tot_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
-                                          "ms_per_profiled_step": round(tot_ms / max(1, len(range(0, args.steps, args.profile_every))), 2)},
-                        "head_linear_gemm": {"launches": sum(e["launches"] for e in heads),
-                                             "ms_per_profiled_step": round(sum(e["ms"] for e in heads) /
-                                                                           max(1, len(range(0, args.steps, args.profile_every))), 3)},
-                        "end_to_end_frac": round(value / world * flop_per_clip / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
-                        "by_kernel": [{"kernel": e["kernel"], "launches": e["launches"],
-                                       "avg_us": round(1e3 * e["ms"] / e["launches"], 2),
-                                       "tflops": round(e["flops"] / (e["ms"] * 1e-3) / 1e12, 2)} for e in prof[:8]]}
+        roofline = roofline_object(prof_samples, max(1, len(range(0, args.steps, args.profile_every))) if args.profile_every > 0 else 1,
+                                   value / world * flop_per_clip / 1e12 / PEAK_FP32_MFMA_TFLOPS)
         line = {
             "metric": "clips/sec (3-seg RGB+Flow+Audio TBN fwd+bwd)" if args.config == 4 and not args.forward_only
             else f"clips/sec (config {args.config}{', forward only' if args.forward_only else ''})",
@@ -445,6 +624,9 @@ def main():
             # mean GPU time per step between the end of the last backbone's backward (entry of the gradient-sync
             # callback on the compute stream) and the return of finish_gradient_sync, max over ranks
             line["exposed_allreduce_ms"] = round(exposed_ms, 3)
+        line["box"] = box
+        if args.profile_every > 0:
+            line["timed_region_instrumented"] = True      # diagnostic run: `value` includes single-stream instrumented steps
         if world == 1 and not args.no_cpu_baseline and args.config == 4 and not args.forward_only:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), file=json_out, flush=True)

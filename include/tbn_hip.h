@@ -43,6 +43,11 @@ int tbn_profile_entry(int i, char* name, int name_len, long* launches, double* t
 /* summed ALGORITHMIC HBM bytes of entry i: per launch the input read once + weights once + output written once (conv /
  * data gradient), dy + x read once + dW written once (weight gradient) -- the denominator of the traffic ratio */
 int tbn_profile_entry_bytes(int i, double* total_alg_bytes);
+/* measurement aid (bench.py `box.mfma_calibration`): ONE launch of a pure v_mfma_f32_32x32x2_f32 register loop
+ * (`workgroups` x 4 waves x `iters` x 16 MFMAs, no memory traffic; sink: any device float, never written) so that a bench
+ * line can state what the box it ran on sustains on the instruction the roofline is priced in.  *flops = the MFMA FLOPs of
+ * the launch.  Replaces nothing in the reference (which publishes no hardware figures). */
+int tbn_diag_mfma_burst(float* sink, int workgroups, int iters, double* flops, void* stream);
 
 /* ---- BN-Inception backbone engine -------------------------------------------------------------
  * replaces: BNInception.features() as instantiated by reference core/models/bn_inception.py:38-107
@@ -77,7 +82,13 @@ typedef struct {
   int bn_grad_layers;         /* 0 none, 1 first BN only ("partialbn", model.py:164-176), 2 all */
   void* aux_stream;           /* optional second hipStream_t (caller-owned): weight-gradient GEMMs run on it,
                                  overlapping the data-gradient / BN-backward chain; joined before return.  NULL = serial.
-                                 Not inside a stream capture (TBN_ERR_UNSUPPORTED): nested capture forks crash ROCm 7.x */
+                                 Not inside a stream capture: tbn_backbone_backward returns TBN_ERR_UNSUPPORTED when its
+                                 launch stream is capturing and aux_stream != NULL.  The fault being fenced off is a NESTED
+                                 fork (a stream that itself joined the capture through an event wait forks the aux stream):
+                                 hipStreamEndCapture of ROCm 7.x then recurses until the stack overflows.  A single-level
+                                 fork from the capture's ORIGIN stream captures fine, but HIP offers no query that tells an
+                                 origin stream from a forked one, so the guard refuses that case too -- broader than the
+                                 fault, by necessity.  The Python host passes NULL while capturing (serial launches). */
 } tbn_backbone_grads;
 
 int tbn_backbone_plan_create(int in_channels, int frames, int height, int width, tbn_backbone_plan** plan);

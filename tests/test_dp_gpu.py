@@ -132,3 +132,88 @@ def test_bench_n2_control_flow_rehearsal():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["config"]["global_batch"] == 4 and d["value"] > 0
     assert d["scaling"] == "weak" and "cpu_baseline" not in d and d["roofline"]["frac"] > 0
+
+
+_RCCL_WORKER = r'''
+import os, sys, math, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from attention_based_tbn_amd.config import load_config, get_modality
+from attention_based_tbn_amd.core.models import DataParallel
+from attention_based_tbn_amd.core.models.model import TBNModel
+from attention_based_tbn_amd.core.utils import FusedSGD
+dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+torch.cuda.set_device(dev)
+dist.init_process_group("nccl", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]), device_id=dev)
+assert dist.get_backend() == "nccl" and dist.get_world_size() == 1
+cfg = load_config(["model.attention.enable=False", "data.audio.audio_length=1.279", "data.sampling=async",
+                   "model.fusion_dropout=0"])
+modality = get_modality(cfg)
+torch.manual_seed(5)
+model = TBNModel(cfg, modality, dev).to(dev)
+crit = {"crossentropy": torch.nn.CrossEntropyLoss()}
+plain = DataParallel(model)                                # the default wrap of a lone rank: a pass-through
+assert not plain.active and plain._hooks == []
+dp = DataParallel(model, force_sync=True)                  # hooks + collectives although the group has one rank
+assert dp.active and dp.world_size == 1 and len(dp._hooks) > 0
+dp.time_sync = True
+calls = []
+_ar = dist.all_reduce
+def counting_all_reduce(t, *a, **k):
+    calls.append(t.numel())
+    return _ar(t, *a, **k)
+dist.all_reduce = counting_all_reduce
+g = torch.Generator().manual_seed(11)
+B, n = 2, 3
+inp = {"RGB": (torch.rand(B, n, 3, 64, 64, generator=g) - 0.45).to(dev),
+       "Flow": (torch.rand(B, n, 10, 64, 64, generator=g) - 0.5).to(dev),
+       "Audio": (torch.randn(B, n, 1, 128, 256, generator=g) * 3 - 6).to(dev)}
+tgt = {"class": {"verb": torch.randint(0, 125, (B,), generator=g).to(dev), "noun": torch.randint(0, 352, (B,), generator=g).to(dev)}}
+model.train()
+params = [p for p in model.parameters() if p.requires_grad]
+opt = FusedSGD(params, lr=0.01, momentum=0.9, weight_decay=0)
+def run(m):
+    for p in model.parameters(): p.grad = None
+    st = {k: v.clone() for k, v in model.state_dict().items()}
+    out = m(inp); loss, _ = m.get_loss(crit, tgt, out, 0); loss["total"].backward()
+    torch.cuda.synchronize()
+    grads = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+    return st, grads, float(loss["total"])
+for step in range(2):
+    with dp.no_sync():
+        st, local, l0 = run(model)                         # hooks off: the un-wrapped model's own gradients
+    model.load_state_dict(st)                              # undo the BN running-statistics update
+    n0 = len(calls)
+    _, synced, l1 = run(dp)                                # hook -> all_reduce(async_op=True) -> queue_callback -> work.wait()
+    # three flat backbone gradients from their hooks + ONE packed small-tensor collective
+    assert len(calls) - n0 == 4, calls[n0:]
+    assert sorted(calls[n0:])[1] > (1 << 18), calls[n0:]
+    assert l0 == l1 and set(local) == set(synced) and len(local) >= 20
+    for k in local:
+        assert torch.equal(local[k], synced[k]), (step, k, float((local[k] - synced[k]).abs().max()))
+    assert dp._pending == [] and dp._fired == set() and not dp._callback_queued and dp._forwards_pending == 0
+    opt.step(clip_grad=20)                                 # the second step runs on updated weights
+torch.cuda.synchronize()
+ms = dp.exposed_sync_ms()
+assert ms is not None and math.isfinite(ms) and ms >= 0.0, ms
+dist.destroy_process_group()
+print("RCCL_W1_OK exposed_allreduce_ms=%.3f" % ms)
+'''
+
+
+def test_gradient_sync_on_real_rccl_world_size_1(tmp_path):
+    """ProcessGroupNCCL (= RCCL) under the gradient-sync path, on the one GPU a development box has: `force_sync`
+    registers the hooks at world size 1, the child is started by torch.distributed.run (fresh process, rendezvous on
+    127.0.0.1) and runs two training steps of the real three-modality model through hook -> all_reduce(async_op=True)
+    -> queue_callback -> work.wait() (a STREAM wait on RCCL; gloo, which every other rehearsal uses, blocks the host).
+    Gradients must equal the un-wrapped model's bit for bit (AVG over one rank, packing and unpacking are exact) and the
+    exposed all-reduce time must be a finite number.  Replaces reference core/models/model_builder.py:73-75."""
+    script = tmp_path / "rccl_w1_worker.py"
+    script.write_text(_RCCL_WORKER)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, OMP_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), str(script), ROOT]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "RCCL_W1_OK" in r.stdout, (r.stdout[-1500:] + "\n----\n" + r.stderr[-3000:])

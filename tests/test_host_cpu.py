@@ -195,6 +195,35 @@ for it, drops in enumerate(steps):
         else:
             assert p.grad is not None and torch.allclose(p.grad, q.grad, atol=1e-6), (it, n)
     assert model._pending == [] and model._fired == set() and not model._callback_queued and bs == 4
+if case != "avg":
+    # TWO training forwards before ONE backward, with opposite draws ("nobody" first, "everybody" second): the count the
+    # ranks exchanged after the first forward no longer describes the backward -> the wrapper must fall back to the
+    # presence flags (ADVICE round 3: the stale "nobody" would have turned the produced gradients into None)
+    model.zero_grad(set_to_none=True); ref.zero_grad(set_to_none=True)
+    model.module.drop = True
+    model(xs)
+    model.module.drop = False
+    loss, _ = model.get_loss(nn.MSELoss(), ys, model(xs), epoch=3)
+    assert model._presence is None and model._forwards_pending == 2
+    loss["total"].backward()
+    ref.drop = False
+    nn.MSELoss()(torch.cat([ref(X[:4]), ref(X[4:])]), Y).backward()
+    for (n, p), (_, q) in zip(model.module.named_parameters(), ref.named_parameters()):
+        assert p.grad is not None and torch.allclose(p.grad, q.grad, atol=1e-6), ("two forwards", n)
+    assert model._forwards_pending == 0 and model._pending == [] and not model._callback_queued
+    if os.environ.get("DP_REPORT", "1") == "1":
+        # a draw that contradicts the gradients (reported "nobody", produced by everybody) must fail loudly, not hang
+        model.zero_grad(set_to_none=True)
+        model.module.drop = True
+        out = model(xs)                                 # exchanged: 0 of 2 replicas
+        model.module.drop = False
+        extra = model.module.c(xs).sum() * 0.0          # ... yet the optional branch takes part in the backward
+        try:
+            (nn.MSELoss()(out, ys) + extra).backward()
+            raise SystemExit("mismatching draw was not detected")
+        except RuntimeError as e:
+            assert "does not match the gradients" in str(e), e
+        assert model._pending == [] and not model._callback_queued and model._forwards_pending == 0
 with model.no_sync():                               # gradients stay local: rank-dependent data -> rank-dependent gradients
     model.zero_grad(set_to_none=True); model.module.drop = False
     nn.MSELoss()(model(xs), ys).backward()

@@ -729,3 +729,88 @@ def test_eval_chunking_config5_shape():
     assert abs(float(one["weights"].sum(-1).mean()) - 1.0) < 1e-5
     for k in ("verb", "noun", "weights"):
         assert rel_err(chunked[k].cpu(), one[k].cpu()) < 1e-5, k
+
+
+def _lone_backbone_for_capture():
+    from attention_based_tbn_amd.core.models.bn_inception import BNInception
+    torch.manual_seed(21)
+    net = BNInception(1000, 3).to(DEV).train()
+    net.use_aux_stream = True                # the default of a lone backbone: weight gradients on a second stream
+    x = torch.randn(4, 3, 64, 64, device=DEV)
+
+    def step():
+        net.zero_grad(set_to_none=True)
+        out = net(x)
+        out.square().mean().backward()
+        return out
+
+    return net, x, step
+
+
+def test_capture_guard_refuses_aux_stream_and_leaves_the_plan_intact(monkeypatch):
+    """`tbn_backbone_backward` refuses an aux stream while its launch stream is capturing (TBN_ERR_UNSUPPORTED: the fix
+    for the SIGSEGV of nested capture forks in ROCm 7.x's hipStreamEndCapture, profiles/r03_graph_capture_multi_aux_rocgdb.log).
+    The Python host passes no aux stream while capturing, so the guard is reached here by hiding the capture from the host
+    check: the C side must raise its message, the capture must end cleanly, and the same backward must then run eagerly
+    with the aux stream and reproduce the earlier gradients bit for bit (plan and event pool intact)."""
+    from attention_based_tbn_amd._lib import TbnHipError
+    net, x, step = _lone_backbone_for_capture()
+    step()                                    # eager: plan creation + autotune (synchronises: not allowed in a capture)
+    torch.cuda.synchronize()
+    g0 = net.flat_weight.grad.clone()
+    rm0 = net.running_mean.clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    raised = None
+    with torch.cuda.stream(side):
+        graph = torch.cuda.CUDAGraph()
+        graph.capture_begin()
+        try:
+            out = net(x)
+            loss = out.square().mean()
+            monkeypatch.setattr(torch.cuda, "is_current_stream_capturing", lambda: False)
+            try:
+                loss.backward()
+            except TbnHipError as e:
+                raised = str(e)
+            finally:
+                monkeypatch.undo()
+        finally:
+            graph.capture_end()               # must not crash: nothing was forked
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    assert raised is not None and "aux_stream inside a stream capture is not supported" in raised, raised
+    assert "rc=-3" in raised, raised          # TBN_ERR_UNSUPPORTED
+    del graph, out, loss
+    net.running_mean.copy_(rm0)
+    step()                                    # eager again, aux stream in use
+    torch.cuda.synchronize()
+    assert torch.equal(net.flat_weight.grad, g0)
+
+
+def test_captured_lone_backbone_train_step_replays_like_eager():
+    """a lone backbone (use_aux_stream = True, the model's policy for one modality) under torch.cuda.graph: the host
+    passes no aux stream while capturing, so the step captures with serial weight-gradient launches (it
+    used to raise from inside autograd) and a replay on NEW input data reproduces the eager step bit for bit."""
+    net, x, step = _lone_backbone_for_capture()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            step()                            # warm-up on the side stream (autotune happens here)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    net.zero_grad(set_to_none=True)
+    with torch.cuda.graph(graph):
+        static_out = step()
+    static_grad = net.flat_weight.grad        # allocated inside the capture: rewritten by every replay
+    x.copy_(torch.randn(x.shape, generator=torch.Generator().manual_seed(5)).to(DEV))
+    graph.replay()
+    torch.cuda.synchronize()
+    got_out, got_grad = static_out.detach().clone(), static_grad.clone()
+    del graph
+    eager_out = step()
+    torch.cuda.synchronize()
+    assert torch.equal(got_out, eager_out.detach()) and torch.equal(got_grad, net.flat_weight.grad)
+    assert float(got_grad.abs().max()) > 0
