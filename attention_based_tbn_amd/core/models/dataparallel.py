@@ -5,7 +5,8 @@ parameter broadcast + scatter/gather + reduce to GPU 0).  Here every rank holds 
 the full forward/backward on its own shard of the clips (per-replica BatchNorm statistics, as
 nn.DataParallel's chunks had) and gradients are averaged with one collective per LARGE parameter
 tensor -- the backbones keep their parameters in a few flat tensors (~41 MB per backbone) -- plus ONE
-for all small tensors (heads, biases, BN affine) packed into a flat buffer: four all-reduces per step.
+for all small tensors (heads, biases, BN affine) packed into a flat buffer; a head tensor above 1 MB (the fusion Linear's
+weight) travels on its own: five all-reduces per step with three modalities.
 A backbone's all-reduce is issued as soon as autograd has accumulated its flat gradient, i.e. while the
 backbones whose backward was enqueued later are still running on their own HIP streams; the packed
 small-tensor collective goes last.  No collective on the data path.
