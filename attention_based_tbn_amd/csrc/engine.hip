@@ -62,6 +62,7 @@ struct Part {
   size_t bpart_off = 0;     // BN-backward partials written by the data-gradient epilogue of conv `red_src`
   int red_src = -1;         // -1: own reduce kernel
   int slot = 0;             // pooled: scratch slot of its forward statistics partials
+  int slot_b = 0;           // the same in branch mode (side-stream work keeps to slots 2 and 3)
 };
 
 struct Conv {   // one GEMM: up to four parts that read the same input (adjacent in the flat parameter arrays)
@@ -72,6 +73,7 @@ struct Conv {   // one GEMM: up to four parts that read the same input (adjacent
   size_t w_off, c_off;
   size_t y_off;                 // training: raw conv output (P x cout); becomes dy in place during backward
   int slot = 0;                 // forward statistics scratch slot
+  int slot_b = 0;               // the same in branch mode (see tbn_backbone_plan::ops_b)
   // forward launch choices, PER MODE ([0] eval epilogue, [1] training epilogue): the two modes are tuned separately and a
   // validation pass at the training shape must not overwrite what training was tuned to (round-2 advisor finding)
   struct FwdTune {
@@ -110,13 +112,18 @@ struct Pool {
 struct BnStep {   // BN (+ReLU) of up to four independent layers: one finalize + one apply launch (three in backward)
   int n;
   int conv[kMaxParts], part[kMaxParts];
+  int slot0 = 0;  // first BN-backward scratch slot (partials, coefficients) of its members: 2 for side-stream steps
 };
 
-enum { OP_CONV = 0, OP_POOL = 1, OP_BN = 2, OP_PREPOOL = 3 };
+// OP_FORK / OP_JOIN only occur in the branch-mode program (ops_b): forward, FORK makes the side stream wait for the
+// launch stream and JOIN the launch stream for the side stream; the backward pass walks the list in reverse with the
+// two exchanged
+enum { OP_CONV = 0, OP_POOL = 1, OP_BN = 2, OP_PREPOOL = 3, OP_FORK = 4, OP_JOIN = 5 };
 struct Op {
   int kind;
   int idx;   // conv / pool / bn-step index; OP_PREPOOL: conv index
   int part;  // OP_PREPOOL: part index
+  int side;  // branch mode: 1 = runs on the side stream
 };
 
 int pool_out(int in, int k, int stride, int pad, bool ceil_mode) {
@@ -142,6 +149,15 @@ struct tbn_backbone_plan {
   std::vector<Pool> pools;
   std::vector<BnStep> bns;
   std::vector<Op> ops;
+  // Branch mode (a side stream is given and nothing is capturing): the same layers as `ops`, ordered and tagged so that
+  // the two independent chains of an inception block run on two streams --
+  //   launch stream: 1x1 group -> BN -> double_3x3_1 -> BN -> double_3x3_2 -> BN
+  //   side stream  : [pool of the block input] -> 3x3 -> [pool_proj] -> BN(3x3, pool_proj)
+  // forked once the 1x1 group's BN is done, joined at the end of the block (reference dataflow
+  // core/models/bn_inception_audio.py:437-1003: the four branches only meet at the concat, :485-493).  One chain's BN /
+  // pool passes and 6-us finalize bubbles then sit under the other chain's GEMMs.  Sibling-pair launches (which put
+  // 3x3 and double_3x3_1 into ONE grid) are not used in this mode.
+  std::vector<Op> ops_b;
   int out_buf;
   size_t weight_floats, chan_floats;
   // workspace layout (float offsets unless noted)
@@ -154,7 +170,7 @@ struct tbn_backbone_plan {
   // fork/join events for the optional aux (weight-gradient) stream; created on first use.  One event per fork (a
   // backward pass never records an event twice: re-recording inside a stream capture is where ROCm 7.2 fell over)
   // + one for the join.
-  static const int kEvents = 72;
+  static const int kEvents = 128;
   hipEvent_t ev[kEvents];
   int n_ev = 0;
 };
@@ -204,7 +220,7 @@ int add_conv(tbn_backbone_plan* P, int nparts, const std::string* names, const i
   c.dgrad_accum = false;
   c.y_off = 0;
   P->convs.push_back(c);
-  Op o = {OP_CONV, (int)P->convs.size() - 1, 0};
+  Op o = {OP_CONV, (int)P->convs.size() - 1, 0, 0};
   P->ops.push_back(o);
   return o.idx;
 }
@@ -220,32 +236,40 @@ int add_pool(tbn_backbone_plan* P, int kind, int inbuf, int outbuf, int out_chof
   p.argmax_off = 0;
   p.bwd_accum = false;
   P->pools.push_back(p);
-  Op o = {OP_POOL, (int)P->pools.size() - 1, 0};
+  Op o = {OP_POOL, (int)P->pools.size() - 1, 0, 0};
   P->ops.push_back(o);
   return o.idx;
 }
 
-void add_bn(tbn_backbone_plan* P, int n, const int* conv, const int* part) {
+// a BN step that only the branch-mode program uses (not appended to `ops`)
+int add_bn_only(tbn_backbone_plan* P, int n, const int* conv, const int* part, int slot0) {
   BnStep s;
   s.n = n;
+  s.slot0 = slot0;
   for (int i = 0; i < n; ++i) {
     s.conv[i] = conv[i];
     s.part[i] = part[i];
   }
   P->bns.push_back(s);
-  Op o = {OP_BN, (int)P->bns.size() - 1, 0};
+  return (int)P->bns.size() - 1;
+}
+
+int add_bn(tbn_backbone_plan* P, int n, const int* conv, const int* part) {
+  const int bi = add_bn_only(P, n, conv, part, 0);
+  Op o = {OP_BN, bi, 0, 0};
   P->ops.push_back(o);
+  return bi;
 }
 
 // BN step over every (non-pooled) part of one conv
-void add_bn_conv(tbn_backbone_plan* P, int ci) {
+int add_bn_conv(tbn_backbone_plan* P, int ci) {
   int cs[kMaxParts], ps[kMaxParts], n = 0;
   for (int i = 0; i < P->convs[ci].nparts; ++i)
     if (!P->convs[ci].parts[i].pooled) {
       cs[n] = ci;
       ps[n++] = i;
     }
-  add_bn(P, n, cs, ps);
+  return add_bn(P, n, cs, ps);
 }
 
 // rows of the GEMM's M dimension per workgroup tile = rows per statistics / reduce partial row: the split-K tile kernel
@@ -312,6 +336,7 @@ bool build_graph(tbn_backbone_plan* P) {
   int x = add_buf(P, h, w, 192);
   add_pool(P, 1, c2, x, 0, 2, 0);
 
+  P->ops_b = P->ops;   // the stem is one chain: same program in both modes
   for (int bi = 0; bi < kNumBlocks; ++bi) {
     const BlockSpec& B = kBlocks[bi];
     const std::string pre = std::string("inception_") + B.name;
@@ -330,7 +355,8 @@ bool build_graph(tbn_backbone_plan* P) {
     // conv commute exactly, so the conv runs on the block input -- as a fourth column range of this GEMM -- and the
     // POOLING runs on its 32..128 output channels instead of the 192..1056 input channels.  The bias is added after
     // the pool (it is folded into the BN statistics / shift like everywhere else), where the reference adds it.
-    int g, g_pp = -1;
+    int g, g_pp = -1, bn_g = -1;
+    int c3 = -1, cd1 = -1, cd2 = -1, cpp = -1, pool_idx = -1, bn_d2 = -1;   // what the branch-mode program refers to
     {
       std::string names[kMaxParts];
       int couts[kMaxParts], db[kMaxParts], dc[kMaxParts], n = 0;
@@ -360,9 +386,9 @@ bool build_graph(tbn_backbone_plan* P) {
       }
       g = add_conv(P, n, names, couts, B.cin, 1, 1, 0, x, db, dc, false);
       if (g_pp >= 0) P->convs[g].parts[g_pp].pooled = true;
-      add_bn_conv(P, g);
+      bn_g = add_bn_conv(P, g);
       if (g_pp >= 0) {
-        Op o = {OP_PREPOOL, g, g_pp};
+        Op o = {OP_PREPOOL, g, g_pp, 0};
         P->ops.push_back(o);
       }
     }
@@ -372,44 +398,85 @@ bool build_graph(tbn_backbone_plan* P) {
     int pool_in = x;
     if (B.pool == 1) {   // 5b: 3x3 / stride-1 max pool of the block input feeds pool_proj (not linear: stays in front)
       const int XP = add_buf(P, h, w, B.cin);
-      add_pool(P, 1, x, XP, 0, 1, 1);
+      pool_idx = add_pool(P, 1, x, XP, 0, 1, 1);
       pool_in = XP;
     }
     {
       std::string n = pre + "_3x3";
       int co = B.c3, db = O, dc = B.c1;
-      mc[nm] = add_conv(P, 1, &n, &co, B.c3r, 3, B.stride, 1, T1, &db, &dc, false);
+      mc[nm] = c3 = add_conv(P, 1, &n, &co, B.c3r, 3, B.stride, 1, T1, &db, &dc, false);
       P->convs[mc[nm]].slot = nm;
+      P->convs[mc[nm]].slot_b = 2;
       mp[nm++] = 0;
     }
     {
       std::string n = pre + "_double_3x3_1";
       int co = B.cd1, db = T3, dc = 0;
-      mc[nm] = add_conv(P, 1, &n, &co, B.cdr, 3, 1, 1, T2, &db, &dc, false);
+      mc[nm] = cd1 = add_conv(P, 1, &n, &co, B.cdr, 3, 1, 1, T2, &db, &dc, false);
       P->convs[mc[nm]].slot = nm;
+      P->convs[mc[nm]].slot_b = 1;
       P->convs[mc[nm]].pair_prev = mc[nm - 1];
       P->convs[mc[nm - 1]].pair_next = mc[nm];
       mp[nm++] = 0;
     }
     if (B.pool == 2) {
       if (pool_out(h, 3, 2, 0, true) != oh || pool_out(w, 3, 2, 0, true) != ow) return false;
-      add_pool(P, 1, x, O, B.c1 + B.c3 + B.cd2, 2, 0);
+      pool_idx = add_pool(P, 1, x, O, B.c1 + B.c3 + B.cd2, 2, 0);
     } else if (B.pool == 0) {
       P->convs[g].parts[g_pp].slot = nm;
+      P->convs[g].parts[g_pp].slot_b = 3;
       mc[nm] = g;
       mp[nm++] = g_pp;
     } else {
       std::string n = pre + "_pool_proj";
       int co = B.cp, db = O, dc = B.c1 + B.c3 + B.cd2;
-      mc[nm] = add_conv(P, 1, &n, &co, B.cin, 1, 1, 0, pool_in, &db, &dc, false);
+      mc[nm] = cpp = add_conv(P, 1, &n, &co, B.cin, 1, 1, 0, pool_in, &db, &dc, false);
       P->convs[mc[nm]].slot = nm;
+      P->convs[mc[nm]].slot_b = 3;
       mp[nm++] = 0;
     }
     add_bn(P, nm, mc, mp);
     {
       std::string n = pre + "_double_3x3_2";
       int co = B.cd2, db = O, dc = B.c1 + B.c3;
-      add_bn_conv(P, add_conv(P, 1, &n, &co, B.cd1, 3, B.stride, 1, T3, &db, &dc, false));
+      cd2 = add_conv(P, 1, &n, &co, B.cd1, 3, B.stride, 1, T3, &db, &dc, false);
+      bn_d2 = add_bn_conv(P, cd2);
+    }
+    {
+      // branch-mode program of this block (see tbn_backbone_plan::ops_b).  Scratch slots: launch-stream layers keep 0 / 1
+      // (1x1 group 0, double_3x3_1 1, double_3x3_2 0), side-stream layers take 2 (3x3) and 3 (pool_proj).
+      auto push = [&](int kind, int idx, int part, int side) {
+        Op o = {kind, idx, part, side};
+        P->ops_b.push_back(o);
+      };
+      push(OP_CONV, g, 0, 0);
+      push(OP_BN, bn_g, 0, 0);
+      push(OP_FORK, 0, 0, 0);
+      int sc[kMaxParts], sp[kMaxParts], sn = 0;
+      sc[sn] = c3;
+      sp[sn++] = 0;
+      if (B.pool == 1) push(OP_POOL, pool_idx, 0, 1);          // 5b: 3x3 / stride-1 max pool of the block input
+      if (g_pp >= 0) {
+        push(OP_PREPOOL, g, g_pp, 1);
+        sc[sn] = g;
+        sp[sn++] = g_pp;
+      }
+      push(OP_CONV, c3, 0, 1);
+      if (cpp >= 0) {
+        push(OP_CONV, cpp, 0, 1);
+        sc[sn] = cpp;
+        sp[sn++] = 0;
+      }
+      if (B.pool == 2) push(OP_POOL, pool_idx, 0, 1);          // 3c / 4e: pass-through max pool into the concat slice
+      push(OP_BN, add_bn_only(P, sn, sc, sp, 2), 0, 1);
+      push(OP_CONV, cd1, 0, 0);
+      {
+        const int z = 0;
+        push(OP_BN, add_bn_only(P, 1, &cd1, &z, 1), 0, 0);
+      }
+      push(OP_CONV, cd2, 0, 0);
+      push(OP_BN, bn_d2, 0, 0);
+      push(OP_JOIN, 0, 0, 0);
     }
     x = O;
     h = oh;
