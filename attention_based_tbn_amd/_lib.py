@@ -19,7 +19,7 @@ class ConvInfo(C.Structure):
 
 class BackboneParams(C.Structure):
     _fields_ = [("weight", c_fp), ("bias", c_fp), ("gamma", c_fp), ("beta", c_fp), ("running_mean", c_fp),
-                ("running_var", c_fp), ("momentum", c_f), ("eps", c_f)]
+                ("running_var", c_fp), ("momentum", c_f), ("eps", c_f), ("side_stream", c_fp)]
 
 
 class BackboneGrads(C.Structure):
@@ -64,6 +64,7 @@ SIGNATURES = {
     "tbn_backbone_channel_floats": (c_sz, [C.c_void_p]),
     "tbn_backbone_workspace_bytes": (c_sz, [C.c_void_p, c_i]),
     "tbn_backbone_out_shape": (c_i, [C.c_void_p, C.POINTER(c_i), C.POINTER(c_i), C.POINTER(c_i)]),
+    "tbn_backbone_num_streams": (c_i, [C.c_void_p]),
     "tbn_backbone_tensor_info": (c_i, [C.c_void_p, C.c_char_p, c_i, C.POINTER(C.c_long), C.POINTER(c_i),
                                        C.POINTER(c_i), C.POINTER(c_i)]),
     "tbn_backbone_launch_info": (c_i, [C.c_void_p, C.c_char_p, c_i, C.POINTER(c_i)]),

@@ -90,7 +90,7 @@ class _BackboneFn(torch.autograd.Function):
         gamma = torch.cat([g0, g1]) if g1.numel() else g0
         beta = torch.cat([b0, b1]) if b1.numel() else b0
         prm = BackboneParams(ptr(weight), ptr(bias), ptr(gamma), ptr(beta), ptr(module.running_mean),
-                             ptr(module.running_var), 0.1, 1e-5)
+                             ptr(module.running_var), 0.1, 1e-5, module._side_stream_ptr())
         feat_ptr = C.c_void_p()
         st = stream_ptr()
         if module.autotune and not plan.tuned[training]:
@@ -141,7 +141,7 @@ class _BackboneFn(torch.autograd.Function):
         dg = torch.zeros_like(gamma) if (bn_first or bn_rest) else None
         dbe = torch.zeros_like(beta) if (bn_first or bn_rest) else None
         prm = BackboneParams(ptr(weight), ptr(bias), ptr(gamma), ptr(beta), ptr(module.running_mean),
-                             ptr(module.running_var), 0.1, 1e-5)
+                             ptr(module.running_var), 0.1, 1e-5, module._side_stream_ptr())
         aux = 0
         # inside a stream capture (torch.cuda.graph of a whole step) the weight gradients stay on the launch stream: the
         # engine refuses an aux stream there (TBN_ERR_UNSUPPORTED -- a capture that forks from an already forked stream
@@ -176,6 +176,10 @@ class BNInception(nn.Module):
         self.autotune = True        # time the GEMM tile candidates per layer on first use of a shape
         self.use_aux_stream = True  # weight-gradient GEMMs on a second HIP stream (overlaps dgrad / BN backward)
         self._aux_streams = {}
+        # branch mode: the 3x3 / pool_proj chain of every inception block on a side stream beside the 1x1 -> double_3x3
+        # chain (include/tbn_hip.h, tbn_backbone_params.side_stream); pays while this backbone is the only one running
+        self.use_branch_streams = True
+        self._side_streams = {}
         self._plans = OrderedDict()
         # layer table from the engine (needs the library, not a GPU)
         probe = C.c_void_p()
@@ -299,6 +303,17 @@ class BNInception(nn.Module):
         else:
             self._plans.move_to_end(key)
         return self._plans[key]
+
+    def _side_stream_ptr(self):
+        """the side stream that goes with the current stream (0: serial program; also while a graph is being captured --
+        the engine would ignore it there anyway)"""
+        if not self.use_branch_streams or torch.cuda.is_current_stream_capturing():
+            return 0
+        cur = torch.cuda.current_stream()
+        s = self._side_streams.get(cur.cuda_stream)
+        if s is None:
+            s = self._side_streams[cur.cuda_stream] = torch.cuda.Stream(device=cur.device)
+        return s.cuda_stream
 
     def _run(self, x, freq_only):
         if not x.is_cuda:

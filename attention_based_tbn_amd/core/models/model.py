@@ -73,6 +73,8 @@ class TBNModel(nn.Module):
             # a second (weight-gradient) stream inside a backbone pays only while it is the sole backbone
             # (measured: +7 % with one modality, 0 / -3 % once the modality streams already fill the GPU)
             getattr(self, "Base_{}".format(m)).use_aux_stream = len(self.modality) == 1
+            # likewise the branch-level side stream inside a backbone (include/tbn_hip.h, tbn_backbone_params.side_stream)
+            getattr(self, "Base_{}".format(m)).use_branch_streams = len(self.modality) == 1
             if cfg.model.freeze_base:
                 self._freeze_base_model(m, freeze_mode=cfg.model.freeze_mode)
 

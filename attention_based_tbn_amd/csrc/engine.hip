@@ -505,6 +505,31 @@ bool build_graph(tbn_backbone_plan* P) {
     }
   }
 
+  // the branch-mode program reorders the layers of a block: it must leave every gradient buffer with the same first
+  // (overwriting) and last (reduce-fusing) writer as the serial program, whose flags the kernels are launched with
+  {
+    std::vector<char> w2(P->bufs.size(), 0);
+    std::vector<int> last2(P->bufs.size(), -1);
+    bool same = true;
+    for (int i = (int)P->ops_b.size() - 1; i >= 0; --i) {
+      const Op& o = P->ops_b[i];
+      if (o.kind == OP_CONV) {
+        const Conv& c = P->convs[o.idx];
+        if (c.need_dgrad) {
+          same = same && (c.dgrad_accum == (w2[c.inbuf] != 0));
+          w2[c.inbuf] = 1;
+          last2[c.inbuf] = o.idx;
+        }
+      } else if (o.kind == OP_POOL) {
+        const Pool& q = P->pools[o.idx];
+        same = same && (q.bwd_accum == (w2[q.inbuf] != 0));
+        w2[q.inbuf] = 1;
+        last2[q.inbuf] = -1;
+      }
+    }
+    if (!same || last2 != last_conv) P->ops_b.clear();   // never expected: branch mode is then simply unavailable
+  }
+
   // conv -> BN -> ReLU -> max pool with no other reader of the BN output (the stem: conv1 -> pool1, conv2_3x3 -> pool2):
   // in training the pool runs inside the BN apply and its backward inside the BN backward, so the full-resolution z
   // and dz tensors (the largest of the network) are never written or re-read.
@@ -816,6 +841,7 @@ size_t tbn_backbone_channel_floats(const tbn_backbone_plan* P) { return P->chan_
 size_t tbn_backbone_workspace_bytes(const tbn_backbone_plan* P, int training) {
   return training ? P->total_bytes_train : P->total_bytes_eval;
 }
+int tbn_backbone_num_streams(const tbn_backbone_plan* P) { return P->ops_b.empty() ? 1 : 2; }
 int tbn_backbone_out_shape(const tbn_backbone_plan* P, int* h, int* w, int* c) {
   const Buf& b = P->bufs[P->out_buf];
   if (h) *h = b.H;
@@ -971,6 +997,19 @@ void fill_wgrad(const tbn_backbone_plan* P, const Conv& c, float* ws, int R, Wgr
   }
 }
 
+// fork / join events of the aux (weight-gradient) and side (branch) streams: created on first use, outside any capture
+int ensure_events(tbn_backbone_plan* PM) {
+  constexpr int NE = tbn_backbone_plan::kEvents;
+  for (int i = PM->n_ev; i < NE; ++i) {
+    if (hipEventCreateWithFlags(&PM->ev[i], hipEventDisableTiming) != hipSuccess) {
+      tbn_set_error("backbone: hipEventCreate failed");
+      return TBN_ERR_LAUNCH;
+    }
+    PM->n_ev = i + 1;
+  }
+  return TBN_OK;
+}
+
 // joins the aux (weight-gradient) stream into the launch stream on every exit path of tbn_backbone_backward
 struct AuxJoin {
   hipStream_t st, aux;
@@ -998,6 +1037,17 @@ int tbn_backbone_forward(const tbn_backbone_plan* P, int training, const float* 
   float* ws = (float*)workspace;
   const int R = P->frames;
   const int tr = training ? 1 : 0;   // index of the forward launch choices (Conv::ft)
+  // branch mode: the caller gave a side stream and nothing is being captured (forks inside a capture: see backward)
+  hipStream_t side = (hipStream_t)prm->side_stream;
+  if (side == st || P->ops_b.empty()) side = nullptr;
+  if (side != nullptr) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) side = nullptr;
+  }
+  const bool br = side != nullptr;
+  tbn_backbone_plan* PM = const_cast<tbn_backbone_plan*>(P);  // event pool only
+  if (br) TBN_TRY(ensure_events(PM));
+  int ev_next = 0;
   float* mean = ws + P->stats_off;
   float* rstd = mean + P->chan_floats;
   float* scale = rstd + P->chan_floats;
@@ -1043,12 +1093,21 @@ int tbn_backbone_forward(const tbn_backbone_plan* P, int training, const float* 
       }
     }
   };
-  for (const Op& o : P->ops) {
+  const hipStream_t st_main = st;
+  for (const Op& o : (br ? P->ops_b : P->ops)) {
+    st = (br && o.side) ? side : st_main;   // the stream this op launches on
+    if (o.kind == OP_FORK || o.kind == OP_JOIN) {
+      // FORK: the side stream continues from here; JOIN: the launch stream waits for the side chain of the block
+      hipEvent_t e = PM->ev[ev_next++];
+      (void)hipEventRecord(e, o.kind == OP_FORK ? st_main : side);
+      (void)hipStreamWaitEvent(o.kind == OP_FORK ? side : st_main, e, 0);
+      continue;
+    }
     if (o.kind == OP_CONV) {
       const Conv& c = P->convs[o.idx];
       const Conv::FwdTune& T = c.ft[tr];
-      if (c.pair_prev >= 0 && P->convs[c.pair_prev].ft[tr].pair) continue;   // ran with its sibling
-      if (c.pair_next >= 0 && T.pair) {
+      if (!br && c.pair_prev >= 0 && P->convs[c.pair_prev].ft[tr].pair) continue;   // ran with its sibling
+      if (!br && c.pair_next >= 0 && T.pair) {
         const Conv& c2 = P->convs[c.pair_next];
         ConvP pa, pb;
         fwd_params(c, pa);
@@ -1067,7 +1126,7 @@ int tbn_backbone_forward(const tbn_backbone_plan* P, int training, const float* 
         p.seg[0].ptr = ws + c.y_off;
         p.seg[0].ld = c.cout;
         p.seg[0].col_begin = 0;
-        p.stat_partial = ws + P->partial_off + (size_t)c.slot * P->partial_floats;
+        p.stat_partial = ws + P->partial_off + (size_t)(br ? c.slot_b : c.slot) * P->partial_floats;
       } else {
         // eval: running-stat BN + ReLU folded into the epilogue, straight into the concat slices; a pooled part
         // (pool_proj) leaves the bare conv output for its average pool
@@ -1096,7 +1155,7 @@ int tbn_backbone_forward(const tbn_backbone_plan* P, int training, const float* 
       if (training) {
         int nparts = 0;
         TBN_TRY(tbn_launch_bn_stats(ws + q.y2_off, q.cout, M, q.cout,
-                                    ws + P->partial_off + (size_t)q.slot * P->partial_floats, &nparts, st));
+                                    ws + P->partial_off + (size_t)(br ? q.slot_b : q.slot) * P->partial_floats, &nparts, st));
       }
     } else if (o.kind == OP_BN) {
       const BnStep& s = P->bns[o.idx];
@@ -1150,17 +1209,17 @@ int tbn_backbone_forward(const tbn_backbone_plan* P, int training, const float* 
         if (q.pooled) {
           L.y = ws + q.y2_off;
           L.y_ld = q.cout;
-          L.partial = ws + P->partial_off + (size_t)q.slot * P->partial_floats;
+          L.partial = ws + P->partial_off + (size_t)(br ? q.slot_b : q.slot) * P->partial_floats;
           L.pld = q.cout;
           L.nparts = tbn_bn_stats_parts(M, q.cout);
         } else {
           L.y = ws + c.y_off + q.col0;
           L.y_ld = c.cout;
-          L.partial = ws + P->partial_off + (size_t)c.slot * P->partial_floats + q.col0;
+          L.partial = ws + P->partial_off + (size_t)(br ? c.slot_b : c.slot) * P->partial_floats + q.col0;
           L.pld = c.cout;
           // M tile of the launch that wrote the statistics partials (a paired launch has its own); training mode here
-          const bool paired_first = c.pair_next >= 0 && c.ft[1].pair;
-          const bool paired_second = c.pair_prev >= 0 && P->convs[c.pair_prev].ft[1].pair;
+          const bool paired_first = !br && c.pair_next >= 0 && c.ft[1].pair;
+          const bool paired_second = !br && c.pair_prev >= 0 && P->convs[c.pair_prev].ft[1].pair;
           int frows = tile_rows(c.ft[1].halo, c.ft[1].mt);
           if (paired_first) frows = 128 * c.ft[1].p_mt;
           if (paired_second) frows = 128 * P->convs[c.pair_prev].ft[1].p_mt;
@@ -1195,6 +1254,7 @@ int tbn_backbone_forward(const tbn_backbone_plan* P, int training, const float* 
       }
     }
   }
+  st = st_main;   // (every block ends with a JOIN: the launch stream has seen all side-stream work)
   *features_out = ws + P->bufs[P->out_buf].off;
   return TBN_OK;
 }
@@ -1439,23 +1499,23 @@ int tbn_backbone_backward(const tbn_backbone_plan* P, const float* dfeatures, co
   tbn_backbone_plan* PM = const_cast<tbn_backbone_plan*>(P);  // event pool only
   if (aux == st) aux = nullptr;
   constexpr int NE = tbn_backbone_plan::kEvents;
-  if (aux != nullptr && PM->n_ev == 0) {
-    for (int i = 0; i < NE; ++i) {
-      if (hipEventCreateWithFlags(&PM->ev[i], hipEventDisableTiming) != hipSuccess) {
-        tbn_set_error("backbone_backward: hipEventCreate failed");
-        return TBN_ERR_LAUNCH;
-      }
-      PM->n_ev = i + 1;
-    }
-  }
-  TBN_REQUIRE(aux == nullptr || (PM->n_ev == NE && (int)P->convs.size() < NE), "backbone_backward: event pool too small");
+  // branch mode (see tbn_backbone_plan::ops_b): a side stream is given and nothing is being captured -- a captured
+  // backward runs the serial program (a fork inside a capture is what the guard below is about)
+  hipStream_t side = (hipStream_t)prm->side_stream;
+  if (side == st || side == aux || P->ops_b.empty()) side = nullptr;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  const bool capturing = hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone;
+  if (capturing) side = nullptr;
+  const bool br = side != nullptr;
+  if ((aux != nullptr || br) && !capturing) TBN_TRY(ensure_events(PM));
+  TBN_REQUIRE((aux == nullptr && !br) || capturing || (PM->n_ev == NE && (int)P->convs.size() + 2 * kNumBlocks + 2 < NE),
+              "backbone_backward: event pool too small");
   if (aux != nullptr) {
     // Forking the weight-gradient stream from a stream that is itself a forked member of a capture (the modality streams
     // of a whole-step hipGraph) makes hipStreamEndCapture of ROCm 7.x (hip::Stream::EndCapture) recurse into itself until
     // the stack overflows -- a SIGSEGV after every call of the step has returned (profiles/r03_graph_capture_multi_aux_rocgdb.log).
     // Whether `st` is the capture's origin (a single-level fork captures fine) cannot be queried: refuse the combination.
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) {
+    if (capturing) {
       tbn_set_error("backbone_backward: aux_stream inside a stream capture is not supported (nested capture forks overflow "
                     "the stack of hipStreamEndCapture in ROCm 7.x): capture with aux_stream = NULL");
       return TBN_ERR_UNSUPPORTED;
@@ -1478,8 +1538,39 @@ int tbn_backbone_backward(const tbn_backbone_plan* P, const float* dfeatures, co
   };
 
   TBN_TRY(tbn_launch_weight_flip_transpose_all(prm->weight, ws + P->wt_off, P->flip, st));
-  for (int oi = (int)P->ops.size() - 1; oi >= 0; --oi) {
-    const Op& o = P->ops[oi];
+  const std::vector<Op>& prog = br ? P->ops_b : P->ops;
+  const hipStream_t st_main = st;
+  // branch mode without an aux stream: the weight gradients share ONE split-K slab region, so those of the side chain
+  // are issued on the launch stream once the side chain has been joined
+  int deferred[8], ndef = 0;
+  auto issue_wgrad = [&](const Conv& c, hipStream_t wst) -> int {
+    tbn_prof_label(("wgrad " + c.parts[c.nparts - 1].name).c_str());
+    WgradP wp;
+    fill_wgrad(P, c, ws, R, &wp);
+    if (c.stem) {
+      float* dwp = ws + P->dwpack_off;
+      TBN_TRY(tbn_launch_wgrad(wp, 1, dwp, ws + P->wsplit_off, wst));
+      if (P->stem_mode == 1) return tbn_launch_unpack_stem_wgrad_rows(dwp, g->dweight + c.w_off, 64, P->cin0, P->kw, wst);
+      return tbn_launch_unpack_stem_wgrad_s2d(dwp, g->dweight + c.w_off, 64, P->cin0, wst);
+    }
+    return tbn_launch_wgrad(wp, 0, g->dweight + c.w_off, ws + P->wsplit_off, wst);
+  };
+  for (int oi = (int)prog.size() - 1; oi >= 0; --oi) {
+    const Op& o = prog[oi];
+    st = (br && o.side) ? side : st_main;   // the stream this op launches on
+    if (o.kind == OP_FORK || o.kind == OP_JOIN) {
+      // reverse walk: a forward JOIN is where the side chain of the block STARTS (the block's output gradient is final),
+      // a forward FORK where it is joined back, ahead of the 1x1 group's BN backward
+      const bool fork = o.kind == OP_JOIN;
+      hipEvent_t e = PM->ev[ev_next++];
+      (void)hipEventRecord(e, fork ? st_main : side);
+      (void)hipStreamWaitEvent(fork ? side : st_main, e, 0);
+      if (!fork) {
+        for (int k = 0; k < ndef; ++k) TBN_TRY(issue_wgrad(P->convs[deferred[k]], st_main));
+        ndef = 0;
+      }
+      continue;
+    }
     if (o.kind == OP_POOL) {
       const Pool& q = P->pools[o.idx];
       const Buf& ib = P->bufs[q.inbuf];
@@ -1555,15 +1646,15 @@ int tbn_backbone_backward(const tbn_backbone_plan* P, const float* dfeatures, co
           const Conv& f = P->convs[q.red_src];
           L.partial = ws + q.bpart_off;
           int dmt = f.d_mt;    // M tile of the launch that wrote the partials (a paired launch has its own tile)
-          if (f.pair_next >= 0 && f.pair_dgrad) dmt = f.pd_mt;
-          if (f.pair_prev >= 0 && P->convs[f.pair_prev].pair_dgrad) dmt = P->convs[f.pair_prev].pd_mt;
-          const bool paired = (f.pair_next >= 0 && f.pair_dgrad) || (f.pair_prev >= 0 && P->convs[f.pair_prev].pair_dgrad);
+          if (!br && f.pair_next >= 0 && f.pair_dgrad) dmt = f.pd_mt;
+          if (!br && f.pair_prev >= 0 && P->convs[f.pair_prev].pair_dgrad) dmt = P->convs[f.pair_prev].pd_mt;
+          const bool paired = !br && ((f.pair_next >= 0 && f.pair_dgrad) || (f.pair_prev >= 0 && P->convs[f.pair_prev].pair_dgrad));
           L.ext_parts = tbn_conv_red_rows(R, f.inH, f.inW, f.stride, paired ? 128 * dmt : tile_rows(f.d_halo, dmt));
         } else {
-          L.partial = partial + (size_t)k * P->partial_floats;
+          L.partial = partial + (size_t)(s.slot0 + k) * P->partial_floats;
           L.ext_parts = 0;
         }
-        L.coef = coef + (size_t)k * 3 * 1024;
+        L.coef = coef + (size_t)(s.slot0 + k) * 3 * 1024;
         const bool first = (s.conv[k] == 0);
         const bool bg = g->dgamma && g->dbeta && (g->bn_grad_layers == 2 || (g->bn_grad_layers == 1 && first));
         L.dgamma = bg ? g->dgamma + q.c_off : nullptr;
@@ -1576,32 +1667,21 @@ int tbn_backbone_backward(const tbn_backbone_plan* P, const float* dfeatures, co
     const Conv& c = P->convs[o.idx];
     // weight gradient -- on the aux stream when given: it only reads dy (final after the BN backward) and
     // the layer input, so it overlaps the data-gradient / BN-backward chain that continues on `st`
-    tbn_prof_label(("wgrad " + c.parts[c.nparts - 1].name).c_str());
-    hipStream_t wst = st;
     if (aux != nullptr) {
       hipEvent_t e = PM->ev[ev_next++];
       (void)hipEventRecord(e, st);
       (void)hipStreamWaitEvent(aux, e, 0);
       join.forked = true;
-      wst = aux;
-    }
-    {
-      WgradP wp;
-      fill_wgrad(P, c, ws, R, &wp);
-      if (c.stem) {
-        float* dwp = ws + P->dwpack_off;
-        TBN_TRY(tbn_launch_wgrad(wp, 1, dwp, ws + P->wsplit_off, wst));
-        if (P->stem_mode == 1)
-          TBN_TRY(tbn_launch_unpack_stem_wgrad_rows(dwp, g->dweight + c.w_off, 64, P->cin0, P->kw, wst));
-        else
-          TBN_TRY(tbn_launch_unpack_stem_wgrad_s2d(dwp, g->dweight + c.w_off, 64, P->cin0, wst));
-      } else {
-        TBN_TRY(tbn_launch_wgrad(wp, 0, g->dweight + c.w_off, ws + P->wsplit_off, wst));
-      }
+      TBN_TRY(issue_wgrad(c, aux));
+    } else if (br && o.side) {
+      TBN_REQUIRE(ndef < 8, "backbone_backward: too many deferred weight gradients");
+      deferred[ndef++] = o.idx;
+    } else {
+      TBN_TRY(issue_wgrad(c, st));
     }
     if (c.need_dgrad) {
-      if (c.pair_prev >= 0 && P->convs[c.pair_prev].pair_dgrad) continue;   // issued with its sibling (next in this walk)
-      if (c.pair_next >= 0 && c.pair_dgrad) {
+      if (!br && c.pair_prev >= 0 && P->convs[c.pair_prev].pair_dgrad) continue;   // issued with its sibling (next in this walk)
+      if (!br && c.pair_next >= 0 && c.pair_dgrad) {
         const Conv& c2 = P->convs[c.pair_next];
         ConvP pa, pb;
         fill_dgrad(P, c, ws, R, &pa);

@@ -352,6 +352,9 @@ def main():
     ap.add_argument("--aux-streams", default=None,
                     help="diagnostic: comma-separated modalities whose weight gradients run on a second stream "
                          "(default: the model's policy -- only a lone backbone)")
+    ap.add_argument("--branch-streams", default=None,
+                    help="diagnostic: comma-separated modalities (or 'all' / 'none') whose inception branches run on a side "
+                         "stream (default: the model's policy -- only a lone backbone)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--host-inputs", action="store_true",
                     help="diagnostic (never the headline): the batch starts in pinned HOST memory every step and is copied "
@@ -490,6 +493,11 @@ def main():
         aux = [m in args.aux_streams.split(",") for m in modality]
     for b_, a_ in zip(bases, aux):
         b_.use_aux_stream = a_
+    if args.branch_streams is not None:
+        want = modality if args.branch_streams == "all" else ([] if args.branch_streams == "none" else args.branch_streams.split(","))
+        for b_, m in zip(bases, modality):
+            b_.use_branch_streams = m in want
+    branch = [b_.use_branch_streams for b_ in bases]
 
     def fence():
         torch.cuda.synchronize()
@@ -537,12 +545,14 @@ def main():
         core.multi_stream = False
         for b_ in bases:
             b_.use_aux_stream = False
+            b_.use_branch_streams = False
         L.tbn_profile_enable(1)
         out = step()
         L.tbn_profile_enable(0)
         core.multi_stream = multi
-        for b_, a_ in zip(bases, aux):
+        for b_, a_, br_ in zip(bases, aux, branch):
             b_.use_aux_stream = a_
+            b_.use_branch_streams = br_
         return out
 
     t0 = time.perf_counter()
@@ -612,6 +622,9 @@ def main():
             "config": {"workload": C_["name"] + (" [forward only]" if args.forward_only and C_["train"] else ""),
                        "batch_per_gpu": B, "global_batch": B * world, "segments": n,
                        "parallelism": f"dp{world}" if world > 1 else "single",
+                       "streams": {"modality_streams": bool(multi and len(modality) > 1),
+                                   "weight_gradient_stream": [m for m, a_ in zip(modality, aux) if a_],
+                                   "branch_streams": [m for m, b_ in zip(modality, branch) if b_]},
                        **({"inputs": "pinned host memory, PCIe copy every step (diagnostic)"} if args.host_inputs else {}),
                        **({"audio_input": "waveform (30695 samples), STFT kernel inside the timed step"} if args.stft_inputs else {})},
             "roofline": roofline,

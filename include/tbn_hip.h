@@ -72,6 +72,17 @@ typedef struct {
   float* running_var;
   float momentum;             /* 0.1 */
   float eps;                  /* 1e-5 */
+  void* side_stream;          /* optional second hipStream_t (caller-owned) for tbn_backbone_forward / _backward: BRANCH MODE.
+                                 The four branches of an inception block only meet at the concat (reference
+                                 core/models/bn_inception_audio.py:437-1003, torch.cat at :485-493 and in every block after);
+                                 with a side stream the 3x3 / pool_proj chain of each block runs on it beside the
+                                 1x1 -> double_3x3 chain on the launch stream (forked after the 1x1 group's BatchNorm, joined
+                                 at the end of the block), so one chain's BN / pool passes sit under the other's GEMMs.
+                                 Every layer runs the kernel the serial program would launch for it alone -- sibling-pair
+                                 launches (3x3 | double_3x3_1 in one grid) are replaced by the two tuned single launches --
+                                 so with pairing off the two programs agree bit for bit (tests/test_branch_gpu.py).  Joined before the
+                                 call returns.  NULL = one chain.  Ignored (serial program) while the launch stream is
+                                 being captured: forks inside a capture are what aux_stream's note below is about. */
 } tbn_backbone_params;
 
 typedef struct {
@@ -99,6 +110,8 @@ size_t tbn_backbone_weight_floats(const tbn_backbone_plan* plan);
 size_t tbn_backbone_channel_floats(const tbn_backbone_plan* plan);
 size_t tbn_backbone_workspace_bytes(const tbn_backbone_plan* plan, int training);
 int tbn_backbone_out_shape(const tbn_backbone_plan* plan, int* h, int* w, int* c);
+/* 2 when the plan holds a branch-mode program (tbn_backbone_params.side_stream is honoured), else 1 */
+int tbn_backbone_num_streams(const tbn_backbone_plan* plan);
 /* test / debug aid: location of one conv's tensors inside the workspace (floats). kind 0: z =
  * relu(bn(conv)) destination slice, 1: BN input y (overwritten by dy in backward), 2: gradient
  * wrt z (offset -1 when it is the caller-supplied dfeatures), 3: the conv's whole input buffer, 4: its training-mode
