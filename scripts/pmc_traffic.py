@@ -59,7 +59,96 @@ def load(path, counter, skip_steps):
     return acc
 
 
+def load_raw(path, skip_steps):
+    """per kernel: launches and summed TCC_EA0_RDREQ / TCC_EA0_RDREQ_32B / TCC_BUBBLE (128-B requests) of the timed steps"""
+    with open(path) as f:
+        rows = [r for r in csv.DictReader(f)]
+    names = {"TCC_EA0_RDREQ_sum": "req", "TCC_EA0_RDREQ_32B_sum": "r32", "TCC_BUBBLE_sum": "r128"}
+    rows = [r for r in rows if r["Counter_Name"] in names]
+    rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+    first, steps_seen, seen_disp = 0, 0, set()
+    for r in rows:
+        if steps_seen >= skip_steps:
+            break
+        d = int(r["Dispatch_Id"])
+        first = d
+        if "opt_sgd_kernel" in r["Kernel_Name"] and d not in seen_disp:
+            steps_seen += 1
+        seen_disp.add(d)
+    acc = defaultdict(lambda: {"disp": set(), "req": 0.0, "r32": 0.0, "r128": 0.0})
+    for r in rows:
+        d = int(r["Dispatch_Id"])
+        if skip_steps and d <= first:
+            continue
+        a = acc[short(r["Kernel_Name"])]
+        a["disp"].add(d)
+        a[names[r["Counter_Name"]]] += float(r["Counter_Value"])
+    return {k: {"launches": len(v["disp"]), "req": v["req"], "r32": v["r32"], "r128": v["r128"]} for k, v in acc.items()}
+
+
+def calibrate(calib_csv, expect_json):
+    """bytes per read request of the class the box's FETCH_SIZE formula prices at 64 B (requests that are neither 32-B nor
+    TCC_BUBBLE's 128-B ones), from launches whose read bytes are KNOWN (scripts/pmc_calibrate.py), per access pattern"""
+    raw = load_raw(calib_csv, 0)
+    with open(expect_json) as f:
+        expect = json.load(f)
+    out = {}
+    for tag, e in expect.items():
+        hits = [(k, v) for k, v in raw.items() if e["kernel_contains"] in k]
+        if not hits:
+            continue
+        k, v = max(hits, key=lambda kv: kv[1]["req"])
+        n = v["launches"]
+        req, r32, r128 = v["req"] / n, v["r32"] / n, v["r128"] / n
+        mid = req - r32 - r128
+        out[tag] = {"kernel": k, "launches": n, "known_read_bytes_per_launch": e["read_bytes_per_launch"],
+                    "rdreq_per_launch": round(req), "rdreq_32B_per_launch": round(r32), "bubble_128B_per_launch": round(r128),
+                    "fetch_size_formula_bytes": round(128 * r128 + 64 * mid + 32 * r32),
+                    "bytes_per_request_of_the_64B_class": round((e["read_bytes_per_launch"] - 128 * r128 - 32 * r32) / max(1.0, mid), 2)}
+    return out
+
+
+def main_raw(argv):
+    """pmc_traffic.py --raw READS.csv WRITES.csv OUT.json SKIP NOTE CALIB.csv CALIB_EXPECT.json
+    READS.csv: a --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_BUBBLE_sum pass of the bench command; WRITES.csv: the
+    WRITE_SIZE pass; CALIB*: the same three read counters over scripts/pmc_calibrate.py and the JSON line it printed."""
+    reads, writes_csv, out_path, skip, note, calib_csv, expect_json = argv[0], argv[1], argv[2], int(argv[3]), argv[4], argv[5], argv[6]
+    cal = calibrate(calib_csv, expect_json)
+    wide = cal.get("wide_copy", {}).get("bytes_per_request_of_the_64B_class", 128.0)
+    wg = cal.get("wgrad_pointwise_64x64", {}).get("bytes_per_request_of_the_64B_class", wide)
+    raw = load_raw(reads, skip)
+    write = load(writes_csv, "WRITE_SIZE", skip)
+    out = {}
+    for k, v in sorted(raw.items()):
+        nw, w = write.get(k, [0, 0.0])
+        if not v["launches"] or not nw:
+            continue
+        n = v["launches"]
+        req, r32, r128 = v["req"] / n, v["r32"] / n, v["r128"] / n
+        f = wg if "conv_wgrad_kernel" in k else wide       # bytes per request of the middle class: by calibrated access pattern
+        rd = 128 * r128 + f * (req - r32 - r128) + 32 * r32
+        wr = 1024.0 * w / nw
+        out[k] = {"launches": n, "rdreq_per_launch": round(req), "rdreq_32B_per_launch": round(r32),
+                  "bubble_128B_per_launch": round(r128), "bytes_per_request_used": f,
+                  "fetch_kib_raw_per_launch": round((128 * r128 + 64 * (req - r32 - r128) + 32 * r32) / 1024.0, 2),
+                  "write_kib_per_launch": round(w / nw, 2), "hbm_read_bytes_per_launch": round(rd),
+                  "hbm_write_bytes_per_launch": round(wr), "hbm_bytes_per_launch": round(rd + wr)}
+    tot = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in out.values())
+    res = {"note": "reads = L2 -> fabric requests (TCC_EA0_RDREQ_sum, _32B_sum, TCC_BUBBLE_sum: one --pmc pass) priced per access "
+                   "pattern with the bytes per request CALIBRATED on launches of known byte counts (`calibration`, "
+                   "scripts/pmc_calibrate.py); writes = WRITE_SIZE (separate pass); per launch over the TIMED steps of bench.py "
+                   f"--steps 3 --warmup 2 --profile-every 1 (B=32; the first {skip} steps are filtered out)" + (" | " + note if note else ""),
+           "source_sha16": source_hash(), "calibration": cal, "total_hbm_bytes_all_launches": tot, "kernels": out}
+    with open(out_path, "w") as f:
+        json.dump(res, f, indent=1)
+    print(json.dumps(cal, indent=1))
+    for k, v in sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"])[:14]:
+        print(f"{k[:70]:70s} n={v['launches']:5d} rd={v['hbm_read_bytes_per_launch']/1e6:9.2f} MB wr={v['hbm_write_bytes_per_launch']/1e6:9.2f} MB")
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--raw":
+        return main_raw(sys.argv[2:])
     skip = int(sys.argv[4]) if len(sys.argv) > 4 else 3
     fetch, write = load(sys.argv[1], "FETCH_SIZE", skip), load(sys.argv[2], "WRITE_SIZE", skip)
     out = {}

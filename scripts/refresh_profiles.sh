@@ -10,6 +10,8 @@ QUICK=${2:-}
 O=gpurun_out
 ROOT=$PWD
 mkdir -p $O
+if [ "$QUICK" = "traffic" ]; then ONLY_TRAFFIC=1; fi
+if [ -z "$ONLY_TRAFFIC" ]; then
 timeout -k 10 400 python bench.py > $O/${TAG}_bench_default.json 2> $O/${TAG}_bench_default.err
 echo "default: $(head -c 200 $O/${TAG}_bench_default.json)"
 if [ -z "$QUICK" ]; then
@@ -33,12 +35,20 @@ cp "$(find /tmp/prof_$TAG -name '*kernel_stats.csv' | head -1)" $ROOT/$O/${TAG}_
 rm -rf /tmp/prof_h_$TAG
 timeout -k 10 500 rocprofv3 --kernel-trace --stats -d /tmp/prof_h_$TAG -o trace --output-format csv -- python3 $ROOT/bench.py --config 3 --stft-inputs --steps 10 --warmup 3 --no-cpu-baseline --profile-every 0 > $ROOT/$O/${TAG}_heads_bench_config3_stft.json 2> /dev/null
 cp "$(find /tmp/prof_h_$TAG -name '*kernel_stats.csv' | head -1)" $ROOT/$O/${TAG}_heads_config3_stft.kernel_stats.csv
-# HBM traffic: FETCH_SIZE and WRITE_SIZE in SEPARATE passes (TCC slots), counters only + kernel trace
-for c in FETCH_SIZE WRITE_SIZE; do
-  rm -rf /tmp/pmc_$c
-  timeout -k 10 500 rocprofv3 --kernel-trace --pmc $c -d /tmp/pmc_$c -o t --output-format csv -- python3 $ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --profile-every 1 > /dev/null 2>&1
-done
-python3 $ROOT/scripts/pmc_traffic.py /tmp/pmc_FETCH_SIZE/t_counter_collection.csv /tmp/pmc_WRITE_SIZE/t_counter_collection.csv $ROOT/$O/${TAG}_pmc_traffic.json 3 "$(cd $ROOT && cat .gitrev 2>/dev/null)" > $ROOT/$O/${TAG}_pmc_traffic_top.txt
+fi
+cd /tmp && export TMPDIR=/tmp
+# HBM traffic: L2 -> fabric read requests by size class (one pass: three TCC counters) and WRITE_SIZE (its own pass), priced
+# with bytes per request calibrated on launches of known byte counts (scripts/pmc_calibrate.py, same three counters)
+traffic() {
+  rm -rf /tmp/pmc_cal /tmp/pmc_RD /tmp/pmc_WRITE_SIZE
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_BUBBLE_sum -d /tmp/pmc_cal -o t --output-format csv -- python3 $ROOT/scripts/pmc_calibrate.py > /tmp/pmc_cal_expect.txt 2> /tmp/pmc_cal.err
+  tail -1 /tmp/pmc_cal_expect.txt > /tmp/pmc_cal_expect.json
+  timeout -k 10 500 rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_BUBBLE_sum -d /tmp/pmc_RD -o t --output-format csv -- python3 $ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --profile-every 1 > /dev/null 2>&1
+  timeout -k 10 500 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/pmc_WRITE_SIZE -o t --output-format csv -- python3 $ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --profile-every 1 > /dev/null 2>&1
+  python3 $ROOT/scripts/pmc_traffic.py --raw "$(find /tmp/pmc_RD -name '*counter_collection.csv' | head -1)" "$(find /tmp/pmc_WRITE_SIZE -name '*counter_collection.csv' | head -1)" $ROOT/$O/${TAG}_pmc_traffic.json 3 "$(cd $ROOT && cat .gitrev 2>/dev/null)" "$(find /tmp/pmc_cal -name '*counter_collection.csv' | head -1)" /tmp/pmc_cal_expect.json > $ROOT/$O/${TAG}_pmc_traffic_top.txt
+}
+traffic
+if [ -n "$ONLY_TRAFFIC" ]; then cd $ROOT; cat $O/${TAG}_pmc_traffic_top.txt; echo done; exit 0; fi
 # heads / STFT traffic (HBM-bound kernels of config 3 from waveforms)
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmch_$c
