@@ -93,13 +93,20 @@ def pmc_traffic(kernel):
             return {"stale": True, "source": src,
                     "why": "kernel sources changed since these counters were collected (source_sha16 mismatch)"}
         k = doc["kernels"].get(kernel)
-        # `read` carries the guide's gfx950 correction (FETCH_SIZE x 2: it counts a 128-B request as 64 B): exact for wide
-        # coalesced reads, an UPPER bound for kernels whose requests are 64 B wide (the weight-gradient kernel: four lanes x
-        # 16 B per pixel row) -- `read_uncorrected` is the matching lower bound
-        return None if k is None else {"hbm_bytes_per_launch": k["hbm_bytes_per_launch"],
-                                        "read": k["hbm_read_bytes_per_launch"], "write": k["hbm_write_bytes_per_launch"],
-                                        "read_uncorrected": round(1024.0 * k["fetch_kib_raw_per_launch"]),
-                                        "source": src}
+        if k is None:
+            return None
+        out = {"hbm_bytes_per_launch": k["hbm_bytes_per_launch"], "read": k["hbm_read_bytes_per_launch"],
+               "write": k["hbm_write_bytes_per_launch"], "source": src}
+        if "calibration" in doc:
+            # reads = L2 -> fabric requests x the bytes per request CALIBRATED on launches of known byte counts in this
+            # kernel's access pattern (scripts/pmc_calibrate.py): the box's FETCH_SIZE formula prices a request at 64 B,
+            # every calibration launch (wide streaming, BN passes, the weight gradient's 64-B row segments) measures 128
+            out["bytes_per_read_request"] = k.get("bytes_per_request_used")
+            out["read_requests_per_launch"] = k.get("rdreq_per_launch")
+            out["calibration_bytes_per_request"] = {t: v["bytes_per_request_of_the_64B_class"] for t, v in doc["calibration"].items()}
+        else:
+            out["read_uncorrected"] = round(1024.0 * k["fetch_kib_raw_per_launch"])
+        return out
     except (OSError, ValueError, KeyError, ImportError):
         return None
 
@@ -196,34 +203,39 @@ def host_cpu():
             "usable_threads": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()}
 
 
-def box_identity(device):
+def query_rocm_smi():
+    """power cap / clocks as rocm-smi reports them, or None.  Called FIRST THING in main(), before anything initialises the
+    GPU in this process (rocm-smi is a child process: a fork + exec), and not at all under a profiler whose preloaded
+    library has initialised the GPU before Python started (rocprofv3 --pmc): the GPU pool refuses an exec from there."""
+    import subprocess
+    if any(k in os.environ.get("LD_PRELOAD", "") for k in ("rocprof", "roctracer", "rocprofiler")) or any(
+            k.startswith(("ROCPROF", "ROCP_", "ROCPROFILER")) for k in os.environ):
+        return None
+    try:
+        r = subprocess.run(["rocm-smi", "--showpower", "--showmaxpower", "--showclocks", "--showperflevel", "--json"],
+                           capture_output=True, text=True, timeout=15)
+        doc = json.loads(r.stdout) if r.returncode == 0 and r.stdout.strip().startswith("{") else None
+        if not doc:
+            return None
+        card = doc.get("card%d" % int(os.environ.get("LOCAL_RANK", "0"))) or next(iter(doc.values()))
+        return {k: v for k, v in card.items()
+                if any(t in k.lower() for t in ("power", "sclk", "mclk", "performance level"))}
+    except (OSError, ValueError, subprocess.SubprocessError, StopIteration):
+        return None
+
+
+def box_identity(device, smi=None):
     """What this line was measured ON, so that two lines from two boxes of a pool explain their own gap: CPU model, GPU
     name, rocm-smi's power cap / clocks when the tool answers, and a warm pure-fp32-MFMA burst (tbn_diag_mfma_burst:
     registers only, no memory traffic) timed after 30 ms of the same load -- a cold burst runs ~12 % slow (DESIGN.md finding
     13) -- as TFLOP/s and as a fraction of the 157.3 the roofline is priced in."""
-    import subprocess
     from attention_based_tbn_amd._lib import call, ptr, stream_ptr
     out = dict(host_cpu())
     out["gpu_name"] = torch.cuda.get_device_name(device)
     props = torch.cuda.get_device_properties(device)
     out["gpu_cus"] = props.multi_processor_count
     out["gpu_arch"] = getattr(props, "gcnArchName", None)
-    try:
-        r = subprocess.run(["rocm-smi", "--showpower", "--showmaxpower", "--showclocks", "--showperflevel", "--json"],
-                           capture_output=True, text=True, timeout=15)
-        doc = json.loads(r.stdout) if r.returncode == 0 and r.stdout.strip().startswith("{") else None
-        if doc:
-            card = doc.get("card%d" % device.index) or next(iter(doc.values()))
-            keep = {}
-            for k, v in card.items():
-                kl = k.lower()
-                if any(t in kl for t in ("power", "sclk", "mclk", "performance level")):
-                    keep[k] = v
-            out["rocm_smi"] = keep
-        else:
-            out["rocm_smi"] = None
-    except (OSError, ValueError, subprocess.SubprocessError, StopIteration):
-        out["rocm_smi"] = None
+    out["rocm_smi"] = smi
     sink = torch.zeros(16, device=device)
     fl = C.c_double()
     wg, iters = 1024, 1500                                     # ~2.6 ms per launch at the nominal peak
@@ -386,6 +398,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    smi = query_rocm_smi() if rank == 0 else None      # before anything in this process touches the GPU
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback)"
     if os.environ.get("TBN_BENCH_BACKEND", "nccl") != "nccl":
         local_rank = local_rank % torch.cuda.device_count()      # rehearsal: ranks share the card(s) present
@@ -511,7 +524,7 @@ def main():
         step()
     L = lib()
     L.tbn_profile_reset()
-    box = box_identity(device) if rank == 0 else None     # CPU / GPU names + a warm pure-MFMA burst: before the timed loop
+    box = box_identity(device, smi) if rank == 0 else None     # CPU / GPU names + a warm pure-MFMA burst: before the timed loop
     probe = None
     if world > 1:
         # one-shot all-reduce probe on a tensor the size of a backbone's flat weight gradient (the largest collective of a

@@ -5,7 +5,7 @@ absolute").  Run under
             -- python3 scripts/pmc_calibrate.py
 and feed DIR/.../t_counter_collection.csv to scripts/pmc_traffic.py --calibration.  Every launch below reads each input byte
 exactly ONCE from a buffer larger than the 256-MiB Infinity Cache, so requests x bytes-per-request must equal the byte count:
-  wide   torch elementwise copy (16 B per lane, 1 KiB per wave instruction)            -> reads numel * 4 B
+  wide   torch elementwise add (16 B per lane, 1 KiB per wave instruction)              -> reads numel * 4 B
   bn     tbn_bn_relu_train_fwd's apply pass (the bn_apply kernels of the step)           -> reads P * C * 4 B (+ statistics pass)
   wgrad  conv_wgrad_kernel<2,2,2> on a pointwise layer with ONE 64 x 64 tile: four lanes x 16 B per pixel row of dy and
          of x, i.e. 64-B segments at a 256-B pitch -- the access shape of the step's dominant kernel
@@ -27,7 +27,7 @@ a = torch.empty(256 * 1024 * 1024, device=dev).normal_()
 b = torch.empty_like(a)
 torch.cuda.synchronize()
 for _ in range(3):
-    b.copy_(a)
+    torch.add(a, 1.0, out=b)          # (a same-dtype copy_ would go through the copy engine, not a kernel)
 torch.cuda.synchronize()
 expect["wide_copy"] = {"kernel_contains": "elementwise", "read_bytes_per_launch": a.numel() * 4, "launches": 3}
 del a, b

@@ -114,8 +114,11 @@ def main_raw(argv):
     WRITE_SIZE pass; CALIB*: the same three read counters over scripts/pmc_calibrate.py and the JSON line it printed."""
     reads, writes_csv, out_path, skip, note, calib_csv, expect_json = argv[0], argv[1], argv[2], int(argv[3]), argv[4], argv[5], argv[6]
     cal = calibrate(calib_csv, expect_json)
-    wide = cal.get("wide_copy", {}).get("bytes_per_request_of_the_64B_class", 128.0)
-    wg = cal.get("wgrad_pointwise_64x64", {}).get("bytes_per_request_of_the_64B_class", wide)
+    def factor(tag, default):
+        v = cal.get(tag, {}).get("bytes_per_request_of_the_64B_class", default)
+        return v if 30.0 <= v <= 130.0 else default      # a calibration launch that was not found / matched a no-read kernel
+    wide = factor("wide_copy", factor("bn_apply", 128.0))
+    wg = factor("wgrad_pointwise_64x64", wide)
     raw = load_raw(reads, skip)
     write = load(writes_csv, "WRITE_SIZE", skip)
     out = {}
