@@ -1118,49 +1118,6 @@ __global__ __launch_bounds__(256) void conv_igemm_phases_kernel(ConvPhases q) {
   conv_igemm_body<MT, NT, false, 3, STAGES, RED>(q.ph[ph], blockIdx.x - q.blk0[ph], lds);
 }
 
-// Sums the split-K slabs of a weight gradient.  256 threads = (256 / SG) float4 outputs x SG slab lanes: lane g adds
-// slabs g, g+SG, ... (two independent chains), the SG partial sums are combined through LDS in fixed order
-// (deterministic).  SG = 16 for many slabs of a small matrix (the 7x7 stem: ~110 slabs of 57 KB) so that the
-// grid still covers the chip; SG = 4 otherwise.  `red`: 256 float4 of LDS; `blk`: reduce workgroup index.
-template <int SG>
-__device__ __forceinline__ void splitk_reduce_body(const float* __restrict__ part, float* __restrict__ out, int n4, int splits,
-                                                   size_t slab4, int blk, float4* red) {
-  constexpr int NO = 256 / SG;
-  const int o = threadIdx.x % NO, g = threadIdx.x / NO;
-  const int i = blk * NO + o;
-  const float4* p4 = reinterpret_cast<const float4*>(part);
-  float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
-  if (i < n4) {
-    int s = g;
-    for (; s + SG < splits; s += 2 * SG) {
-      const float4 u = p4[(size_t)s * slab4 + i], v = p4[(size_t)(s + SG) * slab4 + i];
-      a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
-      b.x += v.x; b.y += v.y; b.z += v.z; b.w += v.w;
-    }
-    if (s < splits) {
-      const float4 u = p4[(size_t)s * slab4 + i];
-      a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
-    }
-    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
-  }
-  red[threadIdx.x] = a;
-  __syncthreads();
-  if (g == 0 && i < n4) {
-#pragma unroll
-    for (int k = 1; k < SG; ++k) {
-      const float4 v = red[k * NO + o];
-      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
-    }
-    reinterpret_cast<float4*>(out)[i] = a;
-  }
-}
-template <int SG>
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, float* __restrict__ out,
-                                                            int n4, int splits, size_t slab4) {
-  __shared__ float4 red[256];
-  splitk_reduce_body<SG>(part, out, n4, splits, slab4, blockIdx.x, red);
-}
-
 // ------------------------------------------------------------------------------------------
 // Weight gradient:  dW[co][tap][ci] = sum_m dy[m][co] * x[pix(m) + tap][ci]
 // GEMM with the *pixel* index as the reduction dim.  Both operands are read as K-major rows
@@ -1192,16 +1149,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
   constexpr int LDSF = (4 * TILE > 4 * 1024 ? 4 * TILE : 4 * 1024);
   __shared__ __attribute__((aligned(16))) float lds[LDSF];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if ((int)blockIdx.x >= p.nblocks) {
-    // rider: the split-K reduce of the previous weight-gradient launch of this backward pass (WgradChain) -- the same
-    // code and summation order as the stand-alone splitk_reduce_kernel, so the result is bit-identical
-    float4* red4 = reinterpret_cast<float4*>(lds);
-    if (p.red_sg == 16)
-      splitk_reduce_body<16>(p.red_part, p.red_out, p.red_n4, p.red_splits, p.red_slab4, (int)blockIdx.x - p.nblocks, red4);
-    else
-      splitk_reduce_body<4>(p.red_part, p.red_out, p.red_n4, p.red_splits, p.red_slab4, (int)blockIdx.x - p.nblocks, red4);
-    return;
-  }
   float* At = lds + wave * TILE;
   float* Bt = At + KR * WA;
 
@@ -1210,7 +1157,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
   // XCD a CONTIGUOUS run of logical ids: a slab is then fetched into one L2 instead of all eight.
   int b;
   {
-    const int nb = p.nblocks, bid = blockIdx.x;
+    const int nb = gridDim.x, bid = blockIdx.x;
     const int q8 = nb >> 3, r8 = nb & 7, xcd = bid & 7, idx = bid >> 3;
     b = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
   }
@@ -1415,6 +1362,44 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
       }
       __syncthreads();
     }
+}
+
+// Sums the split-K slabs of a weight gradient.  256 threads = (256 / SG) float4 outputs x SG slab lanes: lane g adds
+// slabs g, g+SG, ... (two independent chains), the SG partial sums are combined through LDS in fixed order
+// (deterministic).  SG = 16 for many slabs of a small matrix (the 7x7 stem: ~110 slabs of 57 KB) so that the
+// grid still covers the chip; SG = 4 otherwise.
+template <int SG>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, float* __restrict__ out,
+                                                            int n4, int splits, size_t slab4) {
+  constexpr int NO = 256 / SG;
+  __shared__ float4 red[256];
+  const int o = threadIdx.x % NO, g = threadIdx.x / NO;
+  const int i = blockIdx.x * NO + o;
+  const float4* p4 = reinterpret_cast<const float4*>(part);
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+  if (i < n4) {
+    int s = g;
+    for (; s + SG < splits; s += 2 * SG) {
+      const float4 u = p4[(size_t)s * slab4 + i], v = p4[(size_t)(s + SG) * slab4 + i];
+      a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
+      b.x += v.x; b.y += v.y; b.z += v.z; b.w += v.w;
+    }
+    if (s < splits) {
+      const float4 u = p4[(size_t)s * slab4 + i];
+      a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
+    }
+    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+  }
+  red[threadIdx.x] = a;
+  __syncthreads();
+  if (g == 0 && i < n4) {
+#pragma unroll
+    for (int k = 1; k < SG; ++k) {
+      const float4 v = red[k * NO + o];
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    reinterpret_cast<float4*>(out)[i] = a;
+  }
 }
 
 // Wt[ci][T-1-tap][co] = W[co][tap][ci]  (tap-flipped, channel-transposed weights for dgrad)
@@ -1959,7 +1944,7 @@ int tbn_launch_conv_pair(ConvP a, ConvP b, int variant, int mt, int nt, hipStrea
 }
 
 template <int MT, int NT, int MODE>
-static void launch_wgrad(const WgradP& p, int blocks, hipStream_t st) {   // blocks: the whole grid, riders included
+static void launch_wgrad(const WgradP& p, int blocks, hipStream_t st) {
   TBN_LAUNCH((conv_wgrad_kernel<MT, NT, MODE>), dim3(blocks), dim3(256), 0, st, p);
 }
 
@@ -2040,23 +2025,7 @@ size_t tbn_wgrad_workspace_floats(int M, int Cout, int Cin, int taps) {
   return worst;
 }
 
-static void launch_splitk_reduce(const float* part, float* out, int n4, int splits, size_t slab4, int sg, hipStream_t st) {
-  if (sg == 16)
-    hipLaunchKernelGGL(splitk_reduce_kernel<16>, dim3(cdiv(n4, 16)), dim3(256), 0, st, part, out, n4, splits, slab4);
-  else
-    hipLaunchKernelGGL(splitk_reduce_kernel<4>, dim3(cdiv(n4, 64)), dim3(256), 0, st, part, out, n4, splits, slab4);
-}
-
-int tbn_wgrad_chain_flush(WgradChain* chain, hipStream_t st) {
-  if (chain == nullptr || !chain->pending) return TBN_OK;
-  launch_splitk_reduce(chain->part, chain->out, chain->n4, chain->splits, chain->slab4, chain->sg, st);
-  chain->pending = false;
-  TBN_CHECK_LAUNCH("splitk_reduce");
-  return TBN_OK;
-}
-
-int tbn_launch_wgrad(WgradP p, int rowmode, float* dw, float* workspace, hipStream_t st, WgradChain* chain) {
-  if (chain != nullptr) workspace = chain->slab[chain->cur];
+int tbn_launch_wgrad(WgradP p, int rowmode, float* dw, float* workspace, hipStream_t st) {
   TBN_REQUIRE(p.Cin % 4 == 0 && p.Cout % 4 == 0 && p.dy_ld % 4 == 0 && (rowmode || p.x_ld % 4 == 0),
               "wgrad: channel counts / pitches must be multiples of 4");
   TBN_REQUIRE(p.M > 0, "wgrad: empty problem");
@@ -2110,18 +2079,6 @@ int tbn_launch_wgrad(WgradP p, int rowmode, float* dw, float* workspace, hipStre
   TBN_REQUIRE(splits == 1 || workspace != nullptr, "wgrad: split-K needs a workspace");
   p.out = splits > 1 ? workspace : dw;
   const int blocks = p.tiles_co * p.tiles_ci * p.taps * splits;
-  p.nblocks = blocks;
-  int grid = blocks;
-  if (chain != nullptr && chain->pending) {   // the previous launch's reduce rides in this grid
-    p.red_part = chain->part;
-    p.red_out = chain->out;
-    p.red_n4 = chain->n4;
-    p.red_splits = chain->splits;
-    p.red_slab4 = chain->slab4;
-    p.red_sg = chain->sg;
-    grid += cdiv(chain->n4, chain->sg == 16 ? 16 : 64);
-    chain->pending = false;
-  }
   if (p.alg_flops <= 0.0) p.alg_flops = 2.0 * p.M * (double)p.Cout * p.K;
   {
     char nm[64];
@@ -2133,11 +2090,11 @@ int tbn_launch_wgrad(WgradP p, int rowmode, float* dw, float* workspace, hipStre
 #define TBN_CASE(MTv, NTv)                                          \
   if (mt == MTv && nt == NTv) {                                     \
     if (mode == 1)                                                  \
-      launch_wgrad<MTv, NTv, 1>(p, grid, st);                       \
+      launch_wgrad<MTv, NTv, 1>(p, blocks, st);                     \
     else if (mode == 2)                                             \
-      launch_wgrad<MTv, NTv, 2>(p, grid, st);                       \
+      launch_wgrad<MTv, NTv, 2>(p, blocks, st);                     \
     else                                                            \
-      launch_wgrad<MTv, NTv, 0>(p, grid, st);                       \
+      launch_wgrad<MTv, NTv, 0>(p, blocks, st);                     \
   } else
   TBN_CASE(1, 1) TBN_CASE(1, 2) TBN_CASE(1, 3) TBN_CASE(2, 1) TBN_CASE(2, 2) TBN_CASE(2, 3) TBN_CASE(3, 1) TBN_CASE(3, 2)
   TBN_CASE(3, 3) TBN_CASE(5, 1) TBN_CASE(5, 2) {
@@ -2150,20 +2107,11 @@ int tbn_launch_wgrad(WgradP p, int rowmode, float* dw, float* workspace, hipStre
   if (splits > 1) {
     const size_t n = (size_t)p.Cout * p.K;
     const int n4 = (int)(n / 4);
-    const int sg = (splits >= 32 && n4 < 64 * 1024) ? 16 : 4;
-    if (chain != nullptr) {   // carried into the next launch of the chain (or flushed by the caller)
-      chain->pending = true;
-      chain->part = workspace;
-      chain->out = dw;
-      chain->n4 = n4;
-      chain->splits = splits;
-      chain->slab4 = n / 4;
-      chain->sg = sg;
-      chain->cur ^= 1;
-    } else {
-      launch_splitk_reduce(workspace, dw, n4, splits, n / 4, sg, st);
-      TBN_CHECK_LAUNCH("splitk_reduce");
-    }
+    if (splits >= 32 && n4 < 64 * 1024)
+      hipLaunchKernelGGL(splitk_reduce_kernel<16>, dim3(cdiv(n4, 16)), dim3(256), 0, st, workspace, dw, n4, splits, n / 4);
+    else
+      hipLaunchKernelGGL(splitk_reduce_kernel<4>, dim3(cdiv(n4, 64)), dim3(256), 0, st, workspace, dw, n4, splits, n / 4);
+    TBN_CHECK_LAUNCH("splitk_reduce");
   }
   return TBN_OK;
 }

@@ -655,7 +655,7 @@ void plan_memory(tbn_backbone_plan* P) {
       ++f.n;
     }
   P->partial_floats = partial;
-  P->wsplit_floats = (wsplit + 63) / 64 * 64;
+  P->wsplit_floats = wsplit;
   P->wt_floats = wtf;
   P->partial_off = take(TBN_BN_MAXL * partial);   // one region per member of a batched BN step
   P->wpack_off = take((size_t)64 * P->stem_K);
@@ -681,7 +681,7 @@ void plan_memory(tbn_backbone_plan* P) {
       }
   P->coef_off = take(TBN_BN_MAXL * 3 * 1024);
   P->diag_fold_off = take(2 * 2048);
-  P->wsplit_off = take(2 * P->wsplit_floats);   // two slab regions: the reduce of one weight gradient rides in the next one's grid (WgradChain)
+  P->wsplit_off = take(wsplit);
   P->wt_off = take(wtf);
   P->dwpack_off = take((size_t)64 * P->stem_rows * P->kw);
   size_t bytes = off * sizeof(float);
@@ -1543,28 +1543,17 @@ int tbn_backbone_backward(const tbn_backbone_plan* P, const float* dfeatures, co
   // branch mode without an aux stream: the weight gradients share ONE split-K slab region, so those of the side chain
   // are issued on the launch stream once the side chain has been joined
   int deferred[8], ndef = 0;
-  // every weight gradient of this pass is issued on ONE stream, in order (aux if given, else the launch stream): the
-  // split-K reduce of each rides in the grid of the next (132 reduce launches of ~4 us per step left the streams'
-  // dependency chains), only the last one -- the stem's, whose packed result is unpacked right away -- is a launch of its own
-  WgradChain chain;
-  chain.slab[0] = ws + P->wsplit_off;
-  chain.slab[1] = ws + P->wsplit_off + P->wsplit_floats;
-  static const int use_chain = getenv("TBN_WGRAD_CHAIN") ? atoi(getenv("TBN_WGRAD_CHAIN")) : 1;   // A/B runs: 0 = a reduce launch per layer
-  WgradChain* chp = use_chain ? &chain : nullptr;
-  hipStream_t last_wst = st;
   auto issue_wgrad = [&](const Conv& c, hipStream_t wst) -> int {
     tbn_prof_label(("wgrad " + c.parts[c.nparts - 1].name).c_str());
     WgradP wp;
     fill_wgrad(P, c, ws, R, &wp);
-    last_wst = wst;
     if (c.stem) {
       float* dwp = ws + P->dwpack_off;
-      TBN_TRY(tbn_launch_wgrad(wp, 1, dwp, ws + P->wsplit_off, wst, chp));
-      TBN_TRY(tbn_wgrad_chain_flush(chp, wst));
+      TBN_TRY(tbn_launch_wgrad(wp, 1, dwp, ws + P->wsplit_off, wst));
       if (P->stem_mode == 1) return tbn_launch_unpack_stem_wgrad_rows(dwp, g->dweight + c.w_off, 64, P->cin0, P->kw, wst);
       return tbn_launch_unpack_stem_wgrad_s2d(dwp, g->dweight + c.w_off, 64, P->cin0, wst);
     }
-    return tbn_launch_wgrad(wp, 0, g->dweight + c.w_off, ws + P->wsplit_off, wst, chp);
+    return tbn_launch_wgrad(wp, 0, g->dweight + c.w_off, ws + P->wsplit_off, wst);
   };
   for (int oi = (int)prog.size() - 1; oi >= 0; --oi) {
     const Op& o = prog[oi];
@@ -1707,7 +1696,6 @@ int tbn_backbone_backward(const tbn_backbone_plan* P, const float* dfeatures, co
       TBN_TRY(tbn_launch_conv(p, 0, c.d_mt, c.d_nt, st));
     }
   }
-  TBN_TRY(tbn_wgrad_chain_flush(chp, last_wst));   // (the stem flushed already: a no-op unless the walk ended elsewhere)
   return TBN_OK;   // `join` joins the aux stream: everything the caller enqueues on `st` next sees the weight gradients
 }
 

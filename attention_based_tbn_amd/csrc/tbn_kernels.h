@@ -104,26 +104,6 @@ struct WgradP {
   const float* fold_scale;      // -DTBN_DIAG=1 builds only: as ConvP::fold_scale, applied to the staged x operand
   const float* fold_shift;
   int ablate;             // timing ablations, honoured by -DTBN_ABLATE=1 builds only (scripts/wgrad_ablate.py)
-  // filled by tbn_launch_wgrad: workgroups [0, nblocks) compute this layer's tiles; workgroups >= nblocks (if any) sum the
-  // split-K slabs of the PREVIOUS weight-gradient launch of the same chain (WgradChain) -- its reduce rides in this grid
-  // instead of being a launch of its own on the stream's dependency chain
-  int nblocks;
-  const float* red_part;  // slabs of the previous launch [red_splits][red_slab4 float4]
-  float* red_out;
-  int red_n4, red_splits, red_sg;   // red_sg: 4 or 16 slab lanes per output float4 (splitk_reduce_body)
-  size_t red_slab4;
-};
-
-// A backward pass's weight-gradient launches in issue order (ONE stream): the split-K reduce of launch i is carried into
-// the grid of launch i + 1 (slab regions alternate), the last one is flushed as a launch of its own.
-struct WgradChain {
-  float* slab[2];         // two regions of tbn_wgrad_workspace_floats (max over the layers) each
-  int cur = 0;
-  bool pending = false;
-  const float* part = nullptr;
-  float* out = nullptr;
-  int n4 = 0, splits = 0, sg = 4;
-  size_t slab4 = 0;
 };
 
 // optional in-process profiler: every conv-GEMM launch gets a pair of hipEvents on its stream.  The events ride ON the
@@ -152,10 +132,7 @@ int tbn_conv_red_rows(int N, int OH, int OW, int up, int tile_rows);   // tile_r
 size_t tbn_conv_halo_lds_bytes(const ConvP& p, int mt, int nt);   // 0: shape not handled by the LDS-halo kernel
 void tbn_wgrad_plan(int M, int Cout, int Cin, int taps, int* mt, int* nt, int* splits, int* rows_per_split);
 size_t tbn_wgrad_workspace_floats(int M, int Cout, int Cin, int taps);
-// chain == nullptr: the split-K reduce (if any) is launched right behind the weight gradient, `workspace` holds the slabs;
-// chain != nullptr: `workspace` is ignored, see WgradChain (call tbn_wgrad_chain_flush after the last launch)
-int tbn_launch_wgrad(WgradP p, int rowmode, float* dw, float* workspace, hipStream_t st, WgradChain* chain = nullptr);
-int tbn_wgrad_chain_flush(WgradChain* chain, hipStream_t st);
+int tbn_launch_wgrad(WgradP p, int rowmode, float* dw, float* workspace, hipStream_t st);
 int tbn_launch_weight_flip_transpose(const float* w, float* wt, int Cout, int taps, int Cin, hipStream_t st);
 // layer table of the one-launch flip/transpose of every data-gradient weight of a backbone (kernel argument)
 struct FlipTab {
