@@ -102,8 +102,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[MT][
   // 6 steps of the short-K 1x1 groups -- because block-uniform run-time cases (ragged last M tile, accumulate, ReLU,
   // bias) were evaluated per element with selects.  A full tile without those takes the LEAN loop: per element one
   // store (+ 2 VALU for the statistics, + 6 for the reduce); everything else keeps the general loop.
-  const bool lean = tile_full && !scatter &&
-                    (EPI != 0 || ((p.flags & (CONV_FLAG_ACCUM | CONV_FLAG_RELU)) == 0 && p.bias == nullptr));
+  // (round 4: an accumulating data gradient -- the 1x1 groups of 3c / 4e / 5b, whose block input also receives a max
+  //  pool's gradient -- takes the lean loop too, with its 16 old values loaded up front like the reduce's y values: these
+  //  were the slowest data gradients of a backbone, 72-92 TF/s, on the ~450-VALU general loop because of that one flag)
+  const bool lean = tile_full && !scatter && (EPI != 0 || ((p.flags & CONV_FLAG_RELU) == 0 && p.bias == nullptr));
+  const bool accum = (EPI == 0) && (p.flags & CONV_FLAG_ACCUM) != 0;   // block-uniform
   // strided data-gradient phase: output pixel of each tile row, decoded ONCE per row into LDS (was: two magic-number
   // divisions per ELEMENT, ~25 VALU x 16 elements x NT sub-tiles per lane)
   unsigned* opix_tab = reinterpret_cast<unsigned*>(lds + 2 * 4 * BN);
@@ -176,7 +179,12 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[MT][
       for (int i = 0; i < MT; ++i) {
         const unsigned vbase = col_ok ? (unsigned)(mrow0 + i * 32) * (unsigned)old * 4u + col_off : TBN_OOB;
         const unsigned ybase = (RED && red_on && col_ok) ? (unsigned)(mrow0 + i * 32) * (unsigned)yld * 4u + ycol_off : TBN_OOB;
-        float yv[16];
+        float yv[16], ov[16];
+        if (EPI == 0 && accum) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e)
+            ov[e] = tbn_llvm_buffer_load_f32(o_rsrc, (int)vbase, (int)((unsigned)((8 * (e >> 2) + (e & 3)) * old) * 4u), 0);
+        }
         if (RED) {
 #pragma unroll
           for (int e = 0; e < 16; ++e)
@@ -186,6 +194,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[MT][
         for (int e = 0; e < 16; ++e) {
           const int dm = 8 * (e >> 2) + (e & 3);
           float v = acc[i][j][e];
+          if (EPI == 0 && accum) v += ov[e];
           if (EPI == 1) {
             s1 += v;
             s2 = fmaf(v, v, s2);
@@ -1796,9 +1805,25 @@ int tbn_launch_conv(ConvP p, int rowmode, int mt, int nt, hipStream_t st) {
     }
   }
   if (phases.n == 0) return TBN_OK;
+  // longest workgroups first: a phase's K is (its taps) x Cin -- 1, 2, 2 and 4 taps for a 3x3 / stride-2 layer -- and the
+  // dispatcher hands out workgroups in block order, so with the 4-tap phase LAST (parity order) its 4x longer workgroups
+  // started when the others were nearly done and ran the launch's tail alone
+  static const int lpt = getenv("TBN_LPT") ? atoi(getenv("TBN_LPT")) : 1;   // A/B runs: 0 = parity order
+  for (int a = 0; a < phases.n && lpt; ++a)
+    for (int b = a + 1; b < phases.n; ++b)
+      if (phases.ph[b].K > phases.ph[a].K) {
+        const ConvP t = phases.ph[a];
+        phases.ph[a] = phases.ph[b];
+        phases.ph[b] = t;
+      }
   // one tile shape for all phases (picked on the largest one), one launch
   int pmt = mt, pnt = nt;
-  if (pmt <= 0 || pnt <= 0) tbn_conv_pick_tile(phases.ph[0].M, p.Cout, phases.ph[0].K, &pmt, &pnt);
+  if (pmt <= 0 || pnt <= 0) {
+    int big = 0;
+    for (int i = 1; i < phases.n; ++i)
+      if (phases.ph[i].M > phases.ph[big].M) big = i;
+    tbn_conv_pick_tile(phases.ph[big].M, p.Cout, phases.ph[big].K, &pmt, &pnt);
+  }
   const int stages = (p.stages == 1 || p.stages == 2) ? p.stages : ((pmt == 1) ? 2 : 1);
   phases.blk0[0] = 0;
   int red_rows = p.red_row0;
@@ -1915,7 +1940,14 @@ int tbn_launch_conv_pair(ConvP a, ConvP b, int variant, int mt, int nt, hipStrea
     TBN_REQUIRE(la > 0 && lb > 0 && la <= 160 * 1024 && lb <= 160 * 1024, "conv_pair: a member is not an LDS-halo shape");
     lds_bytes = la > lb ? la : lb;
   }
+  // the member with the longer K loop first: its workgroups are the long ones, and the dispatcher hands out workgroups in
+  // block order (a launch should not end with the long workgroups of the second member running alone)
   ConvP* ms[2] = {&a, &b};
+  static const int lpt = getenv("TBN_LPT") ? atoi(getenv("TBN_LPT")) : 1;   // A/B runs: 0 = caller's order
+  if (b.K > a.K && lpt) {
+    ms[0] = &b;
+    ms[1] = &a;
+  }
   for (int i = 0; i < 2; ++i) {
     ms[i]->tiles_m = cdiv(ms[i]->M, 128 * mt);
     ms[i]->tiles_n = cdiv(ms[i]->Cout, 32 * nt);
@@ -1923,8 +1955,8 @@ int tbn_launch_conv_pair(ConvP a, ConvP b, int variant, int mt, int nt, hipStrea
     ms[i]->halo = variant == 0 ? 1 : 0;
     q.m[i] = *ms[i];
   }
-  q.blk1 = a.tiles_m * a.tiles_n;
-  const int blocks = q.blk1 + b.tiles_m * b.tiles_n;
+  q.blk1 = ms[0]->tiles_m * ms[0]->tiles_n;
+  const int blocks = q.blk1 + ms[1]->tiles_m * ms[1]->tiles_n;
   {
     char nm[64];
     const int epi = a.mode == CONV_EPI_STATS ? 1 : (a.mode == CONV_EPI_EVAL ? 2 : 0);

@@ -6,6 +6,7 @@ from attention_based_tbn_amd._lib import lib
 cin, H, W, N = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
 net = BNInception(1000, cin).cuda().train()
 net.use_aux_stream = False   # one stream: an event bracket times exactly one kernel
+net.use_branch_streams = False
 x = torch.randn(N, cin, H, W, device="cuda")
 L = lib()
 for it in range(3):
