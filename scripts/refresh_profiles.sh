@@ -11,9 +11,13 @@ O=gpurun_out
 ROOT=$PWD
 mkdir -p $O
 if [ "$QUICK" = "traffic" ]; then ONLY_TRAFFIC=1; fi
-if [ -z "$ONLY_TRAFFIC" ]; then
-timeout -k 10 400 python bench.py > $O/${TAG}_bench_default.json 2> $O/${TAG}_bench_default.err
+if [ "$QUICK" = "pmc" ]; then ONLY_PMC=1; QUICK=; fi
+if [ "$QUICK" = "bench" ]; then ONLY_BENCH=1; QUICK=; fi
+if [ -z "$ONLY_TRAFFIC" ] && [ -z "$ONLY_PMC" ]; then
+timeout -k 10 400 python bench.py --no-cpu-baseline > $O/${TAG}_bench_default.json 2> $O/${TAG}_bench_default.err
 echo "default: $(head -c 200 $O/${TAG}_bench_default.json)"
+timeout -k 10 400 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/${TAG}_bench_driver_command.json 2> /dev/null
+echo "driver command: $(head -c 200 $O/${TAG}_bench_driver_command.json)"
 if [ -z "$QUICK" ]; then
   for c in 2 3 5; do
     timeout -k 10 300 python bench.py --config $c > $O/${TAG}_bench_config$c.json 2> /dev/null
@@ -36,6 +40,7 @@ rm -rf /tmp/prof_h_$TAG
 timeout -k 10 500 rocprofv3 --kernel-trace --stats -d /tmp/prof_h_$TAG -o trace --output-format csv -- python3 $ROOT/bench.py --config 3 --stft-inputs --steps 10 --warmup 3 --no-cpu-baseline --profile-every 0 > $ROOT/$O/${TAG}_heads_bench_config3_stft.json 2> /dev/null
 cp "$(find /tmp/prof_h_$TAG -name '*kernel_stats.csv' | head -1)" $ROOT/$O/${TAG}_heads_config3_stft.kernel_stats.csv
 fi
+if [ -n "$ONLY_BENCH" ]; then cd $ROOT; echo done; exit 0; fi
 cd /tmp && export TMPDIR=/tmp
 # HBM traffic: L2 -> fabric read requests by size class (one pass: three TCC counters) and WRITE_SIZE (its own pass), priced
 # with bytes per request calibrated on launches of known byte counts (scripts/pmc_calibrate.py, same three counters)
