@@ -1977,7 +1977,10 @@ int tbn_launch_conv_pair(ConvP a, ConvP b, int variant, int mt, int nt, hipStrea
 
 template <int MT, int NT, int MODE>
 static void launch_wgrad(const WgradP& p, int blocks, hipStream_t st) {
-  TBN_LAUNCH((conv_wgrad_kernel<MT, NT, MODE>), dim3(blocks), dim3(256), 0, st, p);
+  // experiment knob (A/B runs only): unused dynamic LDS caps the workgroups per CU (the 64 x 64 tile needs 64 registers and
+  // 34 KB of LDS: four per CU; each split's 54 tile x tap workgroups share an x / dy slab through the XCD's 4-MB L2)
+  static const int pad = getenv("TBN_WGRAD_LDS_PAD") ? atoi(getenv("TBN_WGRAD_LDS_PAD")) : 0;
+  TBN_LAUNCH((conv_wgrad_kernel<MT, NT, MODE>), dim3(blocks), dim3(256), (MT == 2 && NT == 2) ? pad : 0, st, p);
 }
 
 // 32-column sub-tiles per workgroup along one dimension: 3 for 96 (and other odd multiples of 96), else 2 when the
