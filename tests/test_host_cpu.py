@@ -396,3 +396,75 @@ def test_isa_wait_scan_flags_a_wait_right_behind_its_load(tmp_path, capsys):
         out.append(capsys.readouterr().out)
     assert "tightest wait   2 MFMAs" in out[0] and "1 of 1 waits closer than 12" in out[0], out[0]
     assert "tightest wait  18 MFMAs" in out[1] and "0 of 1 waits closer than 12" in out[1], out[1]
+
+
+def test_bench_roofline_is_a_median_over_post_loop_samples():
+    """bench.py host logic (no GPU): `roofline` comes from the instrumented steps run AFTER the timed loop -- dominant kernel
+    by summed time, achieved / conv-stage figures as medians with min / max beside them, head Linear GEMMs kept apart"""
+    import bench
+
+    def sample(scale):
+        return [{"kernel": "conv_wgrad_kernel<2, 2, 0>", "launches": 36, "ms": 3.6 * scale, "flops": 36 * 13.0e9, "alg_bytes": 36 * 50e6},
+                {"kernel": "conv_halo_kernel<1, 1, 1>", "launches": 20, "ms": 1.5 * scale, "flops": 20 * 8.0e9, "alg_bytes": 20 * 30e6},
+                {"kernel": "linear: conv_sk4_kernel<1, 1, 0>", "launches": 6, "ms": 0.1, "flops": 6e9, "alg_bytes": 1e6}]
+    r = bench.roofline_object([sample(1.00), sample(1.10), sample(0.95)], 1, 0.68)
+    assert r["kernel"] == "conv_wgrad_kernel<2, 2, 0>" and r["samples"] == 3 and r["launches"] == 36
+    tf = [36 * 13.0e9 / (3.6e-3 * s) / 1e12 for s in (1.00, 1.10, 0.95)]
+    assert abs(r["achieved"] - sorted(tf)[1]) < 0.01
+    assert abs(r["frac_min"] - min(tf) / bench.PEAK_FP32_MFMA_TFLOPS) < 1e-3 and abs(r["frac_max"] - max(tf) / bench.PEAK_FP32_MFMA_TFLOPS) < 1e-3
+    conv = [(36 * 13.0e9 + 20 * 8.0e9) / (5.1e-3 * s) / 1e12 for s in (1.00, 1.10, 0.95)]
+    assert abs(r["all_conv_gemm"]["achieved"] - sorted(conv)[1]) < 0.01 and r["all_conv_gemm"]["frac_min"] < r["all_conv_gemm"]["frac"] < r["all_conv_gemm"]["frac_max"]
+    assert r["head_linear_gemm"]["launches"] == 6 and r["end_to_end_frac"] == 0.68 and r["kernel_families"]["conv_halo_kernel"] == 20
+    assert bench.roofline_object([], 1, 0.5) is None
+    # the diagnostic in-loop mode (--profile-every): ONE aggregate over several steps, launches reported per step
+    agg = [dict(e, launches=e["launches"] * 4, ms=e["ms"] * 4, flops=e["flops"] * 4, alg_bytes=e["alg_bytes"] * 4) for e in sample(1.0)]
+    r2 = bench.roofline_object([agg], 4, 0.5)
+    assert r2["launches"] == 36 and abs(r2["all_conv_gemm"]["ms_per_profiled_step"] - 5.1) < 0.01
+    cpu = bench.host_cpu()
+    assert cpu["hardware_threads"] >= 1 and (cpu["physical_cores"] is None or cpu["physical_cores"] <= cpu["hardware_threads"])
+
+
+def test_pmc_traffic_prices_requests_with_the_calibration(tmp_path):
+    """scripts/pmc_traffic.py --raw on synthetic rocprofv3 counter CSVs: bytes per request come from the calibration
+    launches of known byte counts (128 here, as on the MI355X), the priming / warm-up steps are cut at the SKIP-th
+    optimiser dispatch, a calibration entry that matched a no-read kernel falls back"""
+    import csv as _csv
+    import subprocess
+    hdr = ["Dispatch_Id", "Kernel_Name", "Counter_Name", "Counter_Value"]
+
+    def write(path, rows):
+        with open(path, "w", newline="") as f:
+            w = _csv.writer(f)
+            w.writerow(hdr)
+            w.writerows(rows)
+
+    def rd(d, k, req, r32=0, bub=0):
+        return [[d, k, "TCC_EA0_RDREQ_sum", req], [d, k, "TCC_EA0_RDREQ_32B_sum", r32], [d, k, "TCC_BUBBLE_sum", bub]]
+    cal = rd(1, "void at::native::vectorized_elementwise_kernel<4, FillFunctor>", 22) + \
+        rd(2, "void conv_wgrad_kernel<2, 2, 2>(WgradP)", 8_000_000) + rd(3, "bn_apply_kernel(float const*)", 6_000_000)
+    write(tmp_path / "cal.csv", cal)
+    expect = {"wide_copy": {"kernel_contains": "elementwise", "read_bytes_per_launch": 1 << 30, "launches": 1},
+              "wgrad_pointwise_64x64": {"kernel_contains": "conv_wgrad_kernel", "read_bytes_per_launch": 8_000_000 * 128, "launches": 1},
+              "bn_apply": {"kernel_contains": "bn_apply_kernel", "read_bytes_per_launch": 6_000_000 * 128, "launches": 1}}
+    (tmp_path / "expect.json").write_text(json.dumps(expect))
+    reads, writes = [], []
+    d = 0
+    for step in range(3):                      # step 0 is cut off (SKIP = 1)
+        for k, req, wkib in (("void conv_wgrad_kernel<2, 2, 0>(WgradP)", 670_000, 12_000.0), ("bn_apply_multi_kernel(BnFwdBatch)", 250_000, 31_000.0),
+                             ("opt_sgd_kernel(OptTab, float)", 1000, 10.0)):
+            d += 1
+            reads += rd(d, k, req * (10 if step == 0 else 1))
+            writes.append([d, k, "WRITE_SIZE", wkib])
+    write(tmp_path / "rd.csv", reads)
+    write(tmp_path / "wr.csv", writes)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "pmc_traffic.py"), "--raw", str(tmp_path / "rd.csv"),
+                        str(tmp_path / "wr.csv"), str(tmp_path / "out.json"), "1", "unit test", str(tmp_path / "cal.csv"),
+                        str(tmp_path / "expect.json")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    doc = json.loads((tmp_path / "out.json").read_text())
+    assert doc["calibration"]["wgrad_pointwise_64x64"]["bytes_per_request_of_the_64B_class"] == 128.0
+    k = doc["kernels"]["conv_wgrad_kernel<2, 2, 0>"]
+    assert k["launches"] == 2 and k["hbm_read_bytes_per_launch"] == 670_000 * 128 and k["hbm_write_bytes_per_launch"] == 12_000 * 1024
+    b = doc["kernels"]["bn_apply_multi_kernel"]
+    assert b["bytes_per_request_used"] == 128.0 and b["hbm_read_bytes_per_launch"] == 250_000 * 128      # wide entry invalid -> bn_apply's
+    assert len(doc["source_sha16"]) == 16
