@@ -169,7 +169,8 @@ class TBNModel(nn.Module):
                 # the heaviest backbone (audio: 5.1 GFLOP per 256x256 frame against 4.1 / 4.6) gets the high-priority
                 # stream: it is the one that finishes last and runs alone at the end of forward and backward (same-box
                 # A/B, 3 of 3: 36.13 -> 35.92 ms per step; issuing it first instead: +-0)
-                st = self._streams[m] = torch.cuda.Stream(device=first.device, priority=(-1 if m == "Audio" else 0))
+                high = os.environ.get("TBN_HIGH_PRIO", "Audio").split(",")      # (A/B knob; the shipped policy is "Audio")
+                st = self._streams[m] = torch.cuda.Stream(device=first.device, priority=(-1 if m in high else 0))
             st.wait_stream(main)
             with torch.cuda.stream(st):
                 raw[m] = run(m)
