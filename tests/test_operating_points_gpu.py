@@ -43,14 +43,16 @@ def _families(L):
     return fam
 
 
-def test_config3_full_batch_train_step_vs_oracle():
-    """BASELINE config 3 at B = 64 clips x 3 segments (R = 192 frames per backbone, RGB + 1.279 s audio, trainable MHA
-    fusion with positional encoding, entropy loss): one training step against the CPU oracle.  Epoch 12 so that the
-    entropy term carries a weight (decay_step 10) and reaches the attention stack's gradients; dropout off (the two
-    sides draw from different generators)."""
+@pytest.mark.parametrize("audio_length,audio_w,T", [(1.279, 256, 8), (2.1, 420, 13)])
+def test_config3_full_batch_train_step_vs_oracle(audio_length, audio_w, T):
+    """BASELINE config 3 at B = 64 clips x 3 segments (R = 192 frames per backbone, RGB + audio, trainable MHA fusion with
+    positional encoding, entropy loss): one training step against the CPU oracle -- with the metric's 1.279 s audio
+    (256 x 256 spectrogram, T = 8: `bench.py --config 3`) and with the reference README's default 2.1 s window (256 x 420,
+    T = 13: `bench.py --config 3 --audio-2p1s`).  Epoch 12 so that the entropy term carries a weight (decay_step 10) and
+    reaches the attention stack's gradients; dropout off (the two sides draw from different generators)."""
     from attention_based_tbn_amd._lib import lib
     from attention_based_tbn_amd.config import load_config, get_modality
-    cfg = load_config(["data.flow.enable=False", "data.audio.audio_length=1.279", "model.attention.use_entropy=True",
+    cfg = load_config(["data.flow.enable=False", f"data.audio.audio_length={audio_length}", "model.attention.use_entropy=True",
                        "model.fusion_dropout=0", "model.attention.attn_dropout=0.0"])
     modality = get_modality(cfg)
     assert modality == ["RGB", "Audio"]
@@ -59,7 +61,7 @@ def test_config3_full_batch_train_step_vs_oracle():
     g = torch.Generator().manual_seed(3)
     mean = torch.tensor([0.408, 0.459, 0.502]).view(1, 1, 3, 1, 1)
     inp = {"RGB": torch.rand(B, n, 3, 224, 224, generator=g) - mean,
-           "Audio": (torch.randn(B, n, 1, 256, 256, generator=g) * 3 - 6).clamp_(-13.8155, 8.0)}
+           "Audio": (torch.randn(B, n, 1, 256, audio_w, generator=g) * 3 - 6).clamp_(-13.8155, 8.0)}
     target = {"class": {"verb": torch.randint(0, 125, (B,), generator=g), "noun": torch.randint(0, 352, (B,), generator=g)}}
     model, crit = build_product(cfg, modality, meta)
     model.train()
@@ -96,7 +98,7 @@ def test_config3_full_batch_train_step_vs_oracle():
     oloss["total"].backward()
     print("oracle step at B = 64 (R = 192 x 2 backbones): %.1f s on %d threads" % (time.time() - t0, torch.get_num_threads()))
     assert bs == obs and set(out) == set(oout) and "weights" in oout
-    assert tuple(out["weights"].shape) == tuple(oout["weights"].shape) == (B * n, 1, 8)
+    assert tuple(out["weights"].shape) == tuple(oout["weights"].shape) == (B * n, 1, T)
     for k in oout:                                   # verb / noun logits and the attention weights
         e = rel_err(out[k].detach().cpu(), oout[k].detach())
         assert e < 1e-3, (k, e)
