@@ -375,6 +375,8 @@ def main():
     ap.add_argument("--branch-streams", default=None,
                     help="diagnostic: comma-separated modalities (or 'all' / 'none') whose inception branches run on a side "
                          "stream (default: the model's policy -- only a lone backbone)")
+    ap.add_argument("--eval-chunk", type=int, default=0,
+                    help="config 5: frames per engine call of the eval forward (default: the backbone's, 256)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--host-inputs", action="store_true",
                     help="diagnostic (never the headline): the batch starts in pinned HOST memory every step and is copied "
@@ -519,6 +521,9 @@ def main():
         for b_, m in zip(bases, modality):
             b_.use_branch_streams = m in want
     branch = [b_.use_branch_streams for b_ in bases]
+    if args.eval_chunk > 0:
+        for b_ in bases:
+            b_.eval_chunk = args.eval_chunk
 
     def fence():
         torch.cuda.synchronize()
