@@ -75,10 +75,10 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
   // 16 channels per workgroup, fixed summation order (tbn_bn_dev.h)
   __shared__ double red[64 * 32];
   const int tid = threadIdx.x;
-  const int c = blockIdx.x * 16 + tid;
+  const int c = blockIdx.x * TBN_FIN_CH + tid;
   double s1, s2;
-  tbn_sum_partials16(partial, C, nparts, blockIdx.x * 16, C, red, &s1, &s2);
-  if (tid < 16 && c < C) {
+  tbn_sum_partials<TBN_FIN_CH>(partial, C, nparts, blockIdx.x * TBN_FIN_CH, C, red, &s1, &s2);
+  if (tid < TBN_FIN_CH && c < C) {
     const double mean = s1 / P;
     double var = s2 / P - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
 int tbn_launch_bn_finalize(const float* partial, int nparts, int P, int C, const float* gamma, const float* beta,
                            const float* conv_bias, float* running_mean, float* running_var, float momentum, float eps,
                            float* save_mean, float* save_rstd, float* scale, float* shift, hipStream_t st) {
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, st, partial, nparts, P, C, gamma, beta,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, TBN_FIN_CH)), dim3(256), 0, st, partial, nparts, P, C, gamma, beta,
                      conv_bias, running_mean, running_var, momentum, eps, save_mean, save_rstd, scale, shift);
   TBN_CHECK_LAUNCH("bn_finalize");
   return TBN_OK;
@@ -545,10 +545,10 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
                                                               float* dgamma, float* dbeta, float* dbias) {
   __shared__ double red[64 * 32];
   const int tid = threadIdx.x;
-  const int c = blockIdx.x * 16 + tid;
+  const int c = blockIdx.x * TBN_FIN_CH + tid;
   double s1, s2;
-  tbn_sum_partials16(partial, C, nparts, blockIdx.x * 16, C, red, &s1, &s2);
-  if (tid < 16 && c < C) {
+  tbn_sum_partials<TBN_FIN_CH>(partial, C, nparts, blockIdx.x * TBN_FIN_CH, C, red, &s1, &s2);
+  if (tid < TBN_FIN_CH && c < C) {
     const double sc = scale[c], rs = rstd[c], mu = mean[c];
     const double bb = -sc * rs * (s2 / P);
     coef[c] = (float)sc;
@@ -564,7 +564,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
 int tbn_launch_bn_bwd_finalize(const float* partial, int nparts, int P, int C, const float* scale, const float* mean,
                                const float* rstd, float* coef, float* dgamma, float* dbeta, float* dbias,
                                hipStream_t st) {
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, st, partial, nparts, P, C, scale, mean,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, TBN_FIN_CH)), dim3(256), 0, st, partial, nparts, P, C, scale, mean,
                      rstd, coef, dgamma, dbeta, dbias);
   TBN_CHECK_LAUNCH("bn_bwd_finalize");
   return TBN_OK;

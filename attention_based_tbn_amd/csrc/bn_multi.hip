@@ -34,10 +34,10 @@ __global__ __launch_bounds__(256) void bn_finalize_multi_kernel(BnFwdBatch b) {
   const int blk = blockIdx.x - b.fin_blk0[li];
   const int C = L.C, P = L.P;
   const int tid = threadIdx.x;
-  const int c = blk * 16 + tid;
+  const int c = blk * TBN_FIN_CH + tid;
   double s1, s2;
-  tbn_sum_partials16(L.partial, L.pld, L.nparts, blk * 16, C, red, &s1, &s2);
-  if (tid < 16 && c < C) {
+  tbn_sum_partials<TBN_FIN_CH>(L.partial, L.pld, L.nparts, blk * TBN_FIN_CH, C, red, &s1, &s2);
+  if (tid < TBN_FIN_CH && c < C) {
     const double mean = s1 / P;
     double var = s2 / P - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -126,7 +126,7 @@ int tbn_launch_bn_fwd_multi(BnFwdBatch& b, hipStream_t st) {
                 "bn_fwd_multi: bad C / pitch / nseg");
     for (int s = 0; s < L.nseg; ++s)
       TBN_REQUIRE(L.seg[s].ld % 4 == 0 && L.seg[s].col_begin % 4 == 0, "bn_fwd_multi: segment pitch/offset must be x4");
-    b.fin_blk0[i + 1] = b.fin_blk0[i] + cdiv(L.C, 16);
+    b.fin_blk0[i + 1] = b.fin_blk0[i] + cdiv(L.C, TBN_FIN_CH);
     L.app_rows = apply_rows(L.P, L.C);
     b.app_blk0[i + 1] = b.app_blk0[i] + cdiv(L.P, L.app_rows);
   }
@@ -197,10 +197,10 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_multi_kernel(BnBwdBatch b
   const int blk = blockIdx.x - b.fin_blk0[li];
   const int C = L.C, P = L.P;
   const int tid = threadIdx.x;
-  const int c = blk * 16 + tid;
+  const int c = blk * TBN_FIN_CH + tid;
   double s1, s2;
-  tbn_sum_partials16(L.partial, C, L.nparts, blk * 16, C, red, &s1, &s2);
-  if (tid < 16 && c < C) {
+  tbn_sum_partials<TBN_FIN_CH>(L.partial, C, L.nparts, blk * TBN_FIN_CH, C, red, &s1, &s2);
+  if (tid < TBN_FIN_CH && c < C) {
     const double sc = L.scale[c], rs = L.rstd[c], mu = L.mean[c];
     const double bb = -sc * rs * (s2 / P);
     L.coef[c] = (float)sc;
@@ -287,7 +287,7 @@ int tbn_launch_bn_bwd_multi(BnBwdBatch& b, hipStream_t st) {
       red_blocks = 0;
     }
     b.red_blk0[i + 1] = b.red_blk0[i] + red_blocks;
-    b.fin_blk0[i + 1] = b.fin_blk0[i] + cdiv(L.C, 16);
+    b.fin_blk0[i + 1] = b.fin_blk0[i] + cdiv(L.C, TBN_FIN_CH);
     L.app_rows = apply_rows(L.P, L.C);
     b.app_blk0[i + 1] = b.app_blk0[i] + cdiv(L.P, L.app_rows);
   }

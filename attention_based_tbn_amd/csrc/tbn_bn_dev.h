@@ -2,26 +2,43 @@
 #pragma once
 #include "tbn_common.h"
 
-// Sums partial[(i*2 + s) * pld + c] over i < nparts for the 16 channels [c0, c0 + 16) and s in {0, 1}.
-// 256 threads = 4 float4 channel quads x 64 row slots: a thread walks rows slot, slot + 64, ... with four independent
-// 16-B loads in flight per statistic (these kernels sit on the conv -> BN -> conv dependency chain and are pure
-// latency: the former 8 channels x 32 slots / scalar-load form took 9 us for 588 rows, 78 us for the stem's 9408),
-// then 32 threads add the 64 slot sums in fixed order -- the result does not depend on scheduling (deterministic).
-// Returns the two sums of channel c0 + tid in threads tid < 16 (others: zeros); `red` = 64*32 doubles of LDS.
-__device__ __forceinline__ void tbn_sum_partials16(const float* __restrict__ partial, int pld, int nparts, int c0, int C,
-                                                   double* red, double* out_s1, double* out_s2) {
-  const int tid = threadIdx.x, cq = tid & 3, slot = tid >> 2;
+// Channels per finalize workgroup (a build-time knob: -DTBN_FIN_CH=4 | 8 | 16).  The finalize kernels sit on the
+// conv -> BN -> conv dependency chain and are pure latency (a step's ~190 of them cost 1.16 ms of step time at ~6 us
+// each, DESIGN.md finding 14): round 2 went from 8 channels x 32 row slots with scalar loads to 16 channels x 64 slots
+// with 16-B loads (9 -> 3 us for 588 rows, -0.97 ms per step).  Round 4 measured the next step of the same idea -- ONE
+// channel quad per workgroup and 256 row slots: 4x the workgroups, one round of loads instead of three for 588 rows --
+// and it bought nothing (same-box A/B, three alternations: 36.05 vs 35.98 ms; config 2 12.31 vs 12.23; config 3 50.53 vs
+// 50.42; profiles/r04_ab_finalize_channels.txt): what a finalize costs now is its launch boundary on the chain, not the
+// rows a thread walks.  16 stays.
+#ifndef TBN_FIN_CH
+#define TBN_FIN_CH 16
+#endif
+
+// Sums partial[(i*2 + s) * pld + c] over i < nparts for the CH channels [c0, c0 + CH) and s in {0, 1}.
+// 256 threads = CH/4 float4 channel quads x S = 1024/CH row slots: a thread walks rows slot, slot + S, ... with four
+// independent 16-B loads in flight per statistic, then the S slot sums are added in a fixed two-level order (groups of 8
+// slots, then the groups): the result does not depend on scheduling (deterministic).
+// Returns the two sums of channel c0 + tid in threads tid < CH (others: zeros); `red` = 2048 doubles of LDS.
+template <int CH>
+__device__ __forceinline__ void tbn_sum_partials(const float* __restrict__ partial, int pld, int nparts, int c0, int C,
+                                                 double* red, double* out_s1, double* out_s2) {
+  constexpr int Q = CH / 4, S = 256 / Q, V = Q * 8, G = S / 8;
+  static_assert(CH == 4 || CH == 8 || CH == 16, "finalize: 4, 8 or 16 channels per workgroup");
+  const int tid = threadIdx.x, cq = tid % Q, slot = tid / Q;
   const int c = c0 + cq * 4;
   double a0 = 0, a1 = 0, a2 = 0, a3 = 0, b0 = 0, b1 = 0, b2 = 0, b3 = 0;
   if (c < C) {
     const float* p = partial + c;
-    int i = slot;
-    for (; i + 192 < nparts; i += 256) {
+    for (int i = slot; i < nparts; i += 4 * S) {
       float4 u[4], v[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        u[k] = *reinterpret_cast<const float4*>(p + ((size_t)(i + 64 * k) * 2 + 0) * pld);
-        v[k] = *reinterpret_cast<const float4*>(p + ((size_t)(i + 64 * k) * 2 + 1) * pld);
+        const int r = i + S * k;
+        const bool ok = r < nparts;
+        const size_t rr = (size_t)(ok ? r : i);          // an in-range row: the load is issued either way
+        u[k] = *reinterpret_cast<const float4*>(p + (rr * 2 + 0) * pld);
+        v[k] = *reinterpret_cast<const float4*>(p + (rr * 2 + 1) * pld);
+        if (!ok) u[k] = v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
       }
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
@@ -29,26 +46,27 @@ __device__ __forceinline__ void tbn_sum_partials16(const float* __restrict__ par
         b0 += (double)v[k].x; b1 += (double)v[k].y; b2 += (double)v[k].z; b3 += (double)v[k].w;
       }
     }
-    for (; i < nparts; i += 64) {
-      const float4 u = *reinterpret_cast<const float4*>(p + ((size_t)i * 2 + 0) * pld);
-      const float4 v = *reinterpret_cast<const float4*>(p + ((size_t)i * 2 + 1) * pld);
-      a0 += (double)u.x; a1 += (double)u.y; a2 += (double)u.z; a3 += (double)u.w;
-      b0 += (double)v.x; b1 += (double)v.y; b2 += (double)v.z; b3 += (double)v.w;
-    }
   }
-  double* r = red + slot * 32 + cq * 4;
+  double* r = red + slot * V + cq * 8;                   // per slot: per quad a0..a3 b0..b3
   r[0] = a0; r[1] = a1; r[2] = a2; r[3] = a3;
-  r[16] = b0; r[17] = b1; r[18] = b2; r[19] = b3;
+  r[4] = b0; r[5] = b1; r[6] = b2; r[7] = b3;
   __syncthreads();
+  const int vi = tid % V, g = tid / V;                   // level 1: value vi of slot group g (8 slots), V * G = 256 threads
   double s = 0.0;
-  if (tid < 32) {
+#pragma unroll
+  for (int k = 0; k < 8; ++k) s += red[(g * 8 + k) * V + vi];
+  __syncthreads();
+  red[g * V + vi] = s;
+  __syncthreads();
+  double t = 0.0;
+  if (tid < V) {                                         // level 2: the G group sums of value tid
 #pragma unroll 8
-    for (int k = 0; k < 64; ++k) s += red[k * 32 + tid];
+    for (int gg = 0; gg < G; ++gg) t += red[gg * V + tid];
   }
-  // threads 0..15 hold S1 of their channel, 16..31 S2: hand S2 over through LDS
   __syncthreads();
-  if (tid >= 16 && tid < 32) red[tid - 16] = s;
+  if (tid < V) red[tid] = t;
   __syncthreads();
-  *out_s1 = (tid < 16) ? s : 0.0;
-  *out_s2 = (tid < 16) ? red[tid] : 0.0;
+  // channel j of the workgroup = quad j / 4, component j % 4: S1 at value (j/4)*8 + j%4, S2 four further
+  *out_s1 = (tid < CH) ? red[(tid >> 2) * 8 + (tid & 3)] : 0.0;
+  *out_s2 = (tid < CH) ? red[(tid >> 2) * 8 + 4 + (tid & 3)] : 0.0;
 }

@@ -7,7 +7,7 @@ cp $L /tmp/orig.so
 for rep in 1 2 3; do
   for v in A B; do
     cp scripts/ab/lib_$v.so $L
-    echo "$v $(python bench.py --steps 40 --warmup 5 --no-cpu-baseline --profile-every 0 2>/dev/null | grep -o 'ms_per_step.: [0-9.]*')"
+    echo "$v $(python bench.py --steps 40 --warmup 5 --no-cpu-baseline --profile-steps 0 2>/dev/null | grep -o 'ms_per_step.: [0-9.]*')"
   done
 done
 cp /tmp/orig.so $L
