@@ -7,6 +7,7 @@
 // triples.  These kernels take up to three layer descriptors as kernel arguments; a workgroup finds its layer
 // with a scalar scan of the block-offset table and then runs the single-layer code of bn.hip on it (same
 // arithmetic, same summation order: results are bit-identical to the per-layer launches).
+#include <cstdlib>
 #include "tbn_common.h"
 #include "tbn_kernels.h"
 #include "tbn_bn_dev.h"
@@ -17,6 +18,21 @@ __device__ __forceinline__ int find_layer(const int* blk0, int n, int b) {
   int l = 0;
   while (l + 1 < n && b >= blk0[l + 1]) ++l;
   return l;
+}
+
+// Timing diagnostics only (-DTBN_DIAG=1 build, never shipped; results are INVALID): TBN_DIAG_SKIP bit 16 drops the forward
+// finalize launches of the batched BN steps, bit 32 the backward ones -- what these ~6-us launches cost the step, per pass
+#ifndef TBN_DIAG
+#define TBN_DIAG 0
+#endif
+inline bool diag_skip_fin(int bit) {
+#if TBN_DIAG
+  static const int mask = getenv("TBN_DIAG_SKIP") ? atoi(getenv("TBN_DIAG_SKIP")) : 0;
+  return (mask & bit) != 0;
+#else
+  (void)bit;
+  return false;
+#endif
 }
 
 inline int ew_grid(size_t items) {
@@ -130,7 +146,7 @@ int tbn_launch_bn_fwd_multi(BnFwdBatch& b, hipStream_t st) {
     L.app_rows = apply_rows(L.P, L.C);
     b.app_blk0[i + 1] = b.app_blk0[i] + cdiv(L.P, L.app_rows);
   }
-  hipLaunchKernelGGL(bn_finalize_multi_kernel, dim3(b.fin_blk0[b.n]), dim3(256), 0, st, b);
+  if (!diag_skip_fin(16)) hipLaunchKernelGGL(bn_finalize_multi_kernel, dim3(b.fin_blk0[b.n]), dim3(256), 0, st, b);
   TBN_CHECK_LAUNCH("bn_finalize_multi");
   hipLaunchKernelGGL(bn_apply_multi_kernel, dim3(b.app_blk0[b.n]), dim3(256), 0, st, b);
   TBN_CHECK_LAUNCH("bn_apply_multi");
@@ -295,7 +311,7 @@ int tbn_launch_bn_bwd_multi(BnBwdBatch& b, hipStream_t st) {
     hipLaunchKernelGGL(bn_bwd_reduce_multi_kernel, dim3(b.red_blk0[b.n]), dim3(256), 0, st, b);
     TBN_CHECK_LAUNCH("bn_bwd_reduce_multi");
   }
-  hipLaunchKernelGGL(bn_bwd_finalize_multi_kernel, dim3(b.fin_blk0[b.n]), dim3(256), 0, st, b);
+  if (!diag_skip_fin(32)) hipLaunchKernelGGL(bn_bwd_finalize_multi_kernel, dim3(b.fin_blk0[b.n]), dim3(256), 0, st, b);
   TBN_CHECK_LAUNCH("bn_bwd_finalize_multi");
   hipLaunchKernelGGL(bn_bwd_apply_multi_kernel, dim3(b.app_blk0[b.n]), dim3(256), 0, st, b);
   TBN_CHECK_LAUNCH("bn_bwd_apply_multi");
