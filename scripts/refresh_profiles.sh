@@ -50,7 +50,7 @@ traffic() {
   tail -1 /tmp/pmc_cal_expect.txt > /tmp/pmc_cal_expect.json
   timeout -k 10 500 rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_BUBBLE_sum -d /tmp/pmc_RD -o t --output-format csv -- python3 $ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --profile-every 1 > /dev/null 2>&1
   timeout -k 10 500 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/pmc_WRITE_SIZE -o t --output-format csv -- python3 $ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --profile-every 1 > /dev/null 2>&1
-  python3 $ROOT/scripts/pmc_traffic.py --raw "$(find /tmp/pmc_RD -name '*counter_collection.csv' | head -1)" "$(find /tmp/pmc_WRITE_SIZE -name '*counter_collection.csv' | head -1)" $ROOT/$O/${TAG}_pmc_traffic.json 3 "$(cd $ROOT && cat .gitrev 2>/dev/null)" "$(find /tmp/pmc_cal -name '*counter_collection.csv' | head -1)" /tmp/pmc_cal_expect.json > $ROOT/$O/${TAG}_pmc_traffic_top.txt
+  python3 $ROOT/scripts/pmc_traffic.py --raw "$(find /tmp/pmc_RD -name '*counter_collection.csv' | head -1)" "$(find /tmp/pmc_WRITE_SIZE -name '*counter_collection.csv' | head -1)" $ROOT/$O/${TAG}_pmc_traffic.json 3 "$(cd $ROOT && cat .gitrev 2>/dev/null || true)" "$(find /tmp/pmc_cal -name '*counter_collection.csv' | head -1)" /tmp/pmc_cal_expect.json > $ROOT/$O/${TAG}_pmc_traffic_top.txt
 }
 traffic
 if [ -n "$ONLY_TRAFFIC" ]; then cd $ROOT; cat $O/${TAG}_pmc_traffic_top.txt; echo done; exit 0; fi
