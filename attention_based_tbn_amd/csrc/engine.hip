@@ -727,6 +727,34 @@ int tbn_backbone_plan_create(int in_channels, int frames, int height, int width,
       return TBN_ERR_UNSUPPORTED;
     }
   }
+  {
+    // every tensor a kernel addresses through ONE buffer descriptor must stay below 2 GiB (32-bit byte offsets with the
+    // hardware range check): refuse here, on the host, what would otherwise fail at some launch in the middle of a pass.
+    // Training cannot chunk the frames (batch statistics); eval callers chunk (BNInception.eval_chunk).
+    size_t worst = (size_t)frames * P->stem_H * P->stem_W * P->cp;                 // the bordered input image
+    const char* what = "network input";
+    for (size_t i = 1; i < P->bufs.size(); ++i) {
+      const size_t n = (size_t)frames * P->bufs[i].H * P->bufs[i].W * P->bufs[i].C;
+      if (n > worst) {
+        worst = n;
+        what = "an activation buffer";
+      }
+    }
+    for (auto& c : P->convs) {
+      const size_t n = (size_t)frames * c.outH * c.outW * c.cout;
+      if (n > worst) {
+        worst = n;
+        what = c.parts[0].name.c_str();
+      }
+    }
+    if (worst * sizeof(float) >= (1ull << 31)) {
+      tbn_set_error("plan_create: %d frames of %dx%d make a %.2f GiB tensor (%s); one engine call addresses at most 2 GiB per "
+                    "tensor -- use fewer frames per call (eval: chunk them; training: a smaller per-GPU batch)",
+                    frames, height, width, (double)(worst * sizeof(float)) / (1ull << 30), what);
+      delete P;
+      return TBN_ERR_UNSUPPORTED;
+    }
+  }
   plan_memory(P);
   *out = P;
   return TBN_OK;

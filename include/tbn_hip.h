@@ -102,6 +102,10 @@ typedef struct {
                                  fault, by necessity.  The Python host passes NULL while capturing (serial launches). */
 } tbn_backbone_grads;
 
+/* TBN_ERR_UNSUPPORTED for input sizes on which the reference graph itself is inconsistent (its torch.cat of the stride-2
+ * branches and the ceil-mode pool of inception_3c / 4e raises) and for frame counts that would make any one tensor of the
+ * pass 2 GiB or larger (32-bit byte offsets under the hardware range check: 511 spectrograms of 256x256 or 668 frames of
+ * 224x224 per call at most; eval callers chunk the frames, a training step needs a smaller per-GPU batch). */
 int tbn_backbone_plan_create(int in_channels, int frames, int height, int width, tbn_backbone_plan** plan);
 void tbn_backbone_plan_destroy(tbn_backbone_plan* plan);
 int tbn_backbone_num_convs(const tbn_backbone_plan* plan);                       /* 69 */

@@ -311,6 +311,11 @@ def test_c_abi_rejects_bad_arguments_before_touching_the_gpu():
     h = C.c_void_p()
     fails(L.tbn_backbone_plan_create(3, 1, 16, 16, C.byref(h)), "unsupported shape")
     fails(L.tbn_backbone_plan_create(3, 1, 75, 91, C.byref(h)), "not a valid BN-Inception size")
+    # one engine call addresses at most 2 GiB per tensor: refused when the plan is made, not at some launch mid-pass
+    fails(L.tbn_backbone_plan_create(1, 512, 256, 256, C.byref(h)), "at most 2 GiB per tensor")
+    fails(L.tbn_backbone_plan_create(3, 700, 224, 224, C.byref(h)), "at most 2 GiB per tensor")
+    assert L.tbn_backbone_plan_create(1, 511, 256, 256, C.byref(h)) == 0      # the largest audio batch of one call
+    L.tbn_backbone_plan_destroy(h)
     # frames pipeline: box / crop outside their parent, stack not dividing the frame count
     fails(L.tbn_frames_to_tensor(bad, 4, 64, 64, 3, 10, 10, 60, 60, 32, 32, 0, 0, 32, 32, 0, 1, None, None, 0, 1, bad, None),
           "outside the 64x64 frame")
