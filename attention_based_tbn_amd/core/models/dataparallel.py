@@ -173,6 +173,7 @@ class DataParallel(nn.Module):
         """average every gradient produced by this backward across ranks (RCCL all-reduce): one collective per
         large (flat backbone) tensor -- already in flight when `overlap` -- and ONE for all the small head /
         bias / BN tensors together.  Runs as the autograd engine's final callback, before backward() returns."""
+        self._check_peer_flag()
         avg, op = self._reduce_op()
         ev0 = None
         if self.time_sync and torch.cuda.is_available():
@@ -181,18 +182,24 @@ class DataParallel(nn.Module):
         optional = getattr(self, "_optional", set())
         count = getattr(self, "_count", None)
         nobody = count == 0                  # known before backward: no replica used the optional parameters
+        mismatch = False
         if count is not None:
             # the exchanged draw must describe THIS backward: a rank whose optional parameters fired although "nobody"
             # kept them (or did not although "all" did) would issue a different collective schedule than its peers and
-            # hang the job inside RCCL -- fail here, loudly, instead
+            # hang the job inside RCCL -- fail loudly instead, and (round-4 advisor) fail on EVERY rank:
             produced = [id(p) in self._fired and p.grad is not None
                         for p in self.module.parameters() if id(p) in getattr(self, "_optional_all", set())]
-            if (count == 0 and any(produced)) or (count == self.world_size and not all(produced)):
-                self._pending, self._fired, self._callback_queued, self._presence, self._count = [], set(), False, None, None
-                self._forwards_pending = 0
-                raise RuntimeError("DataParallel: the optional-parameter draw exchanged after forward (%d of %d replicas) "
-                                   "does not match the gradients this backward produced; one forward per backward is "
-                                   "assumed when the module reports its draw" % (count, self.world_size))
+            if count == self.world_size and not all(produced):
+                # the peers reduced the optional tensors from their gradient hooks, in hook order; this rank's hooks never
+                # fired, so it cannot join those collectives in order any more.  Drain what is in flight (nothing may
+                # still be writing p.grad when the exception unwinds), then take the communicator down so that the peers'
+                # collectives fail now instead of at the RCCL timeout (torch implements abort for the nccl backend only)
+                self._drain_and_reset()
+                self._abort_group()
+                raise RuntimeError(self._MISMATCH % (count, self.world_size))
+            # "nobody" was exchanged but this rank produced them: the peers' schedule (optional tensors skipped) is one
+            # this rank can follow exactly -- it does, with a flag in the packed buffer, and all ranks raise together
+            mismatch = count == 0 and any(produced)
         in_flight = {id(p) for p, _ in self._pending}
         params = [p for p in self.module.parameters() if p.requires_grad]      # registration order: rank independent
         present = {}
@@ -203,7 +210,9 @@ class DataParallel(nn.Module):
                     p.grad = torch.zeros_like(p)         # this rank dropped it: contributes zeros, same schedule
         # a non-optional parameter without a gradient is skipped -- on every rank alike (same contract as torch DDP
         # with find_unused_parameters=False); small ones still travel (as zeros) so that the packed size is fixed
-        late_large = [p for p in params if p.numel() >= self.SMALL and id(p) not in in_flight and p.grad is not None]
+        # ("nobody": the optional tensors are skipped -- also on a rank whose backward produced them against the draw)
+        late_large = [p for p in params if p.numel() >= self.SMALL and id(p) not in in_flight and p.grad is not None
+                      and not (nobody and id(p) in optional)]
         small = [p for p in params if p.numel() < self.SMALL]
         works = [w for _, w in self._pending]
         works += [dist.all_reduce(p.grad, op=op, group=self.process_group, async_op=True) for p in late_large]
@@ -212,7 +221,10 @@ class DataParallel(nn.Module):
         if small or opt_list:
             ref = (small or opt_list)[0]
             pieces = [(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in small]
-            flags = torch.tensor([1.0 if present[id(p)] else 0.0 for p in opt_list], dtype=ref.dtype, device=ref.device)
+            flags = [1.0 if present[id(p)] else 0.0 for p in opt_list]
+            if count is not None:
+                flags.append(1.0 if mismatch else 0.0)       # some rank's gradients contradict the exchanged draw
+            flags = torch.tensor(flags, dtype=ref.dtype, device=ref.device)
             flat = torch.cat(pieces + [flags])
             works.append(dist.all_reduce(flat, op=op, group=self.process_group, async_op=True))
         for work in works:
@@ -239,6 +251,8 @@ class DataParallel(nn.Module):
                 for p, a in zip(opt_list, anyone):
                     if not a:
                         p.grad = None                      # no replica produced it: the optimiser skips it
+            if count is not None:
+                self._stash_peer_flag(flat[-1:])           # read at the NEXT forward / backward: no end-of-step host sync
         if ev0 is not None:
             ev1.record()
             self._sync_events.append((ev0, ev1))
@@ -248,6 +262,61 @@ class DataParallel(nn.Module):
         self._presence = None
         self._count = None
         self._forwards_pending = 0
+        if mismatch:
+            # this rank followed the peers' schedule, i.e. its optional gradients were NOT reduced: drop them (the peers
+            # hold None as well, so the replicas stay identical) and fail here; the peers fail at their next forward /
+            # backward, when they read the flag that travelled in the packed buffer
+            for p in self.module.parameters():
+                if id(p) in getattr(self, "_optional_all", set()):
+                    p.grad = None
+            self._peer_flag = None
+            raise RuntimeError(self._MISMATCH % (count, self.world_size))
+
+    def _stash_peer_flag(self, flag):
+        if flag.is_cuda:
+            host = torch.zeros(1, dtype=flag.dtype).pin_memory()
+            host.copy_(flag, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._peer_flag = (ev, host, flag)          # `flag` kept alive until the copy has run
+        else:
+            self._peer_flag = (None, flag.clone(), None)
+
+    def _check_peer_flag(self):
+        """raises when some rank reported, in the previous synchronised backward, gradients that contradict the exchanged
+        draw (that rank raised right away; this one learns it from the flag in the packed buffer -- checked one call
+        later so that no step ends in a host-device synchronisation)"""
+        pf, self._peer_flag = getattr(self, "_peer_flag", None), None
+        if pf is None:
+            return
+        if pf[0] is not None:
+            pf[0].synchronize()
+        if float(pf[1][0]) > 0:
+            self._drain_and_reset()
+            raise RuntimeError(self._MISMATCH % (-1, self.world_size) + " (reported by a peer rank in the previous step)")
+
+    _MISMATCH = ("DataParallel: the optional-parameter draw exchanged after forward (%d of %d replicas) does not match the "
+                 "gradients this backward produced on some rank; one forward per backward is assumed when the module "
+                 "reports its draw")
+
+    def _drain_and_reset(self):
+        """error paths: wait for every collective already issued on p.grad (an exception must not leave RCCL writing
+        into gradients the caller may free or reuse), then clear the per-step state"""
+        for _, work in self._pending:
+            try:
+                work.wait()
+            except Exception:      # the collective itself failed: nothing left to drain
+                pass
+        self._pending, self._fired, self._callback_queued, self._presence, self._count = [], set(), False, None, None
+        self._forwards_pending = 0
+
+    def _abort_group(self):
+        try:
+            if dist.get_backend(self.process_group) == "nccl":
+                from torch.distributed.distributed_c10d import _abort_process_group
+                _abort_process_group(self.process_group)
+        except Exception:          # best effort: the RuntimeError raised next is the message that matters
+            pass
 
     def exposed_sync_ms(self):
         """mean GPU time the compute stream spent inside finish_gradient_sync (the all-reduce tail that backward did
@@ -259,6 +328,8 @@ class DataParallel(nn.Module):
         return sum(ms) / len(ms)
 
     def forward(self, *args, **kwargs):
+        if self.active:
+            self._check_peer_flag()
         out = self.module(*args, **kwargs)
         if self.active and self._sync and self.module.training and torch.is_grad_enabled():
             # the module's draw is per forward, the exchange describes ONE forward: when a second training forward

@@ -73,9 +73,14 @@ def clip_grad_norm_(parameters, max_norm, norm_type=2.0):
 
 class FusedSGD(torch.optim.Optimizer):
     """`torch.optim.SGD(params, lr, momentum, weight_decay)` (dampening 0, no Nesterov) as one multi-tensor HIP
-    launch per step; `step(clip_grad=max_norm)` additionally folds `clip_grad_norm_` into the update (the
-    gradients are read once; they are NOT rescaled in memory in that mode) and stores the norm in
-    `self.last_total_norm` (device tensor)."""
+    launch per step.  `step(clip_grad=max_norm)` additionally runs `clip_grad_norm_` (norm in `self.last_total_norm`,
+    a device tensor) and is equivalent to the reference's `clip_grad_norm_(...)` + `optimizer.step()`
+    (core/tools/train.py:84-94) in every schedule: the gradients are rescaled IN MEMORY, so what a later backward
+    accumulates onto them (accumulator_step > 1, train.py:71-72) is what the reference accumulates onto.
+    `step(clip_grad=max_norm, grads_consumed=True)` folds the clip coefficient into the update instead (gradients read
+    once, NOT rescaled in memory: one launch and one pass over the gradients fewer) -- only for callers that clear the
+    gradients before the next backward (accumulator_step == 1: `TrainStep`, `bench.py`); under accumulation it would
+    silently differ from the reference, which is why it is opt-in."""
 
     def __init__(self, params, lr, momentum=0.0, weight_decay=0.0):
         if lr < 0.0 or momentum < 0.0 or weight_decay < 0.0:
@@ -86,7 +91,7 @@ class FusedSGD(torch.optim.Optimizer):
         self.last_total_norm = None
 
     @torch.no_grad()
-    def step(self, closure=None, clip_grad=None):
+    def step(self, closure=None, clip_grad=None, grads_consumed=False):
         loss = None
         if closure is not None:
             with torch.enable_grad():
@@ -95,7 +100,12 @@ class FusedSGD(torch.optim.Optimizer):
         if clip_grad:
             allp = [p for g in self.param_groups for p in g["params"] if p.grad is not None]
             if allp:
-                self.last_total_norm, gscale = _sqnorm_coef(_entries(allp, False), clip_grad, allp[0].device)
+                ents = _entries(allp, False)
+                self.last_total_norm, gscale = _sqnorm_coef(ents, clip_grad, allp[0].device)
+                if not grads_consumed:
+                    for a, n in _chunks(ents):
+                        call("tbn_opt_scale_grads", a, n, ptr(gscale), stream_ptr())
+                    gscale = None
         for group in self.param_groups:
             params = [p for p in group["params"] if p.grad is not None]
             if not params:

@@ -504,7 +504,7 @@ def main():
         out = model(inp)
         loss, _ = model.get_loss(criterion, tgt, out, 0)
         loss["total"].backward()              # N>1: gradient all-reduce is issued inside backward, waited at its end
-        opt.step(clip_grad=cfg.train.clip_grad)   # clip_grad_norm_(20) + SGD(momentum) in three HIP launches
+        opt.step(clip_grad=cfg.train.clip_grad, grads_consumed=True)   # clip_grad_norm_(20) + SGD(momentum) in three HIP launches (zero_grad precedes every backward)
         return loss["total"].detach()      # no reference to the autograd graph survives the step
 
     if world > 1 and hasattr(model, "time_sync"):

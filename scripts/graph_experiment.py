@@ -27,7 +27,7 @@ def step():
     out = model(inp)
     loss, _ = model.get_loss(criterion, tgt, out, 0)
     loss["total"].backward()
-    opt.step(clip_grad=cfg.train.clip_grad)
+    opt.step(clip_grad=cfg.train.clip_grad, grads_consumed=True)
     return loss["total"]
 
 def timeit(fn, reps):

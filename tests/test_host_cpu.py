@@ -224,6 +224,30 @@ if case != "avg":
         except RuntimeError as e:
             assert "does not match the gradients" in str(e), e
         assert model._pending == [] and not model._callback_queued and model._forwards_pending == 0
+        # ONE rank contradicts the draw (rank 1 alone produces the gradients nobody announced): it follows the peers'
+        # schedule, raises at once and drops the gradients that were not reduced; rank 0 completes its backward and
+        # learns it from the flag in the packed buffer at its next forward -- every rank fails loudly, nobody hangs
+        model.zero_grad(set_to_none=True)
+        model.module.drop = True
+        out = model(xs)
+        model.module.drop = False
+        loss1 = nn.MSELoss()(out, ys)
+        if rank == 1:
+            loss1 = loss1 + model.module.c(xs).sum() * 0.0
+        try:
+            loss1.backward()
+            raised = False
+        except RuntimeError as e:
+            raised = "does not match the gradients" in str(e)
+        assert raised == (rank == 1), raised
+        assert all(p.grad is None for n, p in model.module.named_parameters() if n.startswith("c."))
+        assert model._pending == [] and not model._callback_queued
+        if rank == 0:
+            try:
+                model(xs)
+                raise SystemExit("the peer's mismatch flag was not seen")
+            except RuntimeError as e:
+                assert "peer rank" in str(e), e
 with model.no_sync():                               # gradients stay local: rank-dependent data -> rank-dependent gradients
     model.zero_grad(set_to_none=True); model.module.drop = False
     nn.MSELoss()(model(xs), ys).backward()
@@ -263,6 +287,90 @@ def test_dataparallel_gradient_average_gloo_world2(tmp_path, overlap, case):
     outs = [p.communicate(timeout=240)[0] for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and f"DP_OK {r}" in o, o
+
+
+_ACC_WORKER = r'''
+import os, sys, copy, torch, torch.distributed as dist, torch.nn as nn
+sys.path.insert(0, sys.argv[1])
+from attention_based_tbn_amd.core.models.dataparallel import DataParallel
+from attention_based_tbn_amd.core.utils.train_step import TrainStep
+dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+rank = dist.get_rank()
+k, clip = int(os.environ["ACC_K"]), float(os.environ["ACC_CLIP"])
+class Toy(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.a = nn.Linear(8, 16); self.b = nn.Linear(16, 2)
+    def forward(self, x): return self.b(torch.relu(self.a(x)))
+    def get_loss(self, criterion, target, preds, epoch=0): return {"total": criterion(preds, target) * 50.0}, preds.shape[0]
+torch.manual_seed(5)
+DataParallel.SMALL = 64                             # a.weight (128 elements) takes the "large tensor" route
+model = DataParallel(Toy())
+ref = copy.deepcopy(model.module)
+opt = torch.optim.SGD(model.parameters(), 0.05, momentum=0.9, weight_decay=1e-3)
+ropt = torch.optim.SGD(ref.parameters(), 0.05, momentum=0.9, weight_decay=1e-3)
+calls = []
+real = dist.all_reduce
+def counting(t, *a, **kw):
+    calls.append(t.numel())
+    return real(t, *a, **kw)
+dist.all_reduce = counting
+step = TrainStep(model, opt, nn.MSELoss(), accumulator_step=k, clip_grad=clip if clip > 0 else None)
+g = torch.Generator().manual_seed(11)
+clipped = 0
+for it in range(7):
+    X = torch.randn(8, 8, generator=g); Y = torch.randn(8, 2, generator=g)
+    n0 = len(calls)
+    loss, bs = step(it, X[rank * 4:(rank + 1) * 4], Y[rank * 4:(rank + 1) * 4], epoch=0)
+    exchanged = len(calls) > n0
+    # the reference loop body, literally (core/tools/train.py:66-94), on the full batch in one process
+    if (it + 1) % k == 0:
+        ropt.zero_grad()
+    rl = ref.get_loss(nn.MSELoss(), Y, ref(X))[0]["total"] / k
+    rl.backward()
+    if clip > 0:
+        tn = torch.nn.utils.clip_grad_norm_(ref.parameters(), clip)
+        clipped += int(tn > clip)
+    stepping = (it + 1) % k == k - 1
+    if stepping:
+        ropt.step()
+    # gradient exchange: every iteration when the clip needs the global accumulated gradient, else on stepping ones only
+    assert exchanged == (clip > 0 or stepping), (it, exchanged)
+    assert step.synced[-1] == exchanged
+    if exchanged:
+        assert len(calls) - n0 == 2, calls[n0:]     # a.weight from its hook + the packed small tensors
+        for (n, p), q in zip(model.module.named_parameters(), ref.parameters()):
+            assert torch.allclose(p.grad, q.grad, rtol=1e-4, atol=2e-5), (it, n)
+    for (n, p), q in zip(model.module.named_parameters(), ref.parameters()):
+        assert torch.allclose(p, q, rtol=1e-4, atol=2e-5), (it, n, float((p - q).abs().max()))
+        mb, rb = opt.state[p].get("momentum_buffer"), ropt.state[q].get("momentum_buffer")
+        assert (mb is None) == (rb is None) and (mb is None or torch.allclose(mb, rb, rtol=1e-4, atol=2e-5)), (it, n)
+assert clip == 0 or clipped >= 3, clipped           # the clip really bit (also on re-clipped accumulated gradients)
+print("ACC_OK", rank)
+'''
+
+
+@pytest.mark.parametrize("k,clip", [(1, 2.0), (2, 0.0), (2, 2.0), (3, 0.0), (3, 2.0)])
+def test_accumulation_schedule_gloo_world2(tmp_path, k, clip):
+    """`TrainStep` (reference core/tools/train.py:66-94) under data parallelism, 2 gloo ranks, seven iterations at
+    accumulator_step = k against the reference loop body run literally on the full batch in one process: parameters and
+    momentum buffers agree after every iteration; without clipping the gradient all-reduce happens on the stepping
+    iterations only (`DataParallel.no_sync()` elsewhere), with clipping on every iteration (the clip coefficient is a
+    function of the GLOBAL accumulated gradient)"""
+    script = tmp_path / "acc_worker.py"
+    script.write_text(_ACC_WORKER)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   OMP_NUM_THREADS="1", ACC_K=str(k), ACC_CLIP=str(clip))
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"ACC_OK {r}" in o, o
 
 
 def test_plan_create_accepts_exactly_the_sizes_the_reference_graph_accepts():

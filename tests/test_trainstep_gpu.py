@@ -19,7 +19,7 @@ def _load():
     return z, [torch.nn.Parameter(torch.from_numpy(z["p0_%d" % i].astype(np.float32)).to(DEV)) for i in range(3)]
 
 
-@pytest.mark.parametrize("fused_clip", [False, True])
+@pytest.mark.parametrize("fused_clip", [False, True, "consumed"])
 def test_fused_sgd_and_clip_match_torch_golden(fused_clip):
     from attention_based_tbn_amd.core.utils import FusedSGD, clip_grad_norm_
     z, params = _load()
@@ -31,8 +31,17 @@ def test_fused_sgd_and_clip_match_torch_golden(fused_clip):
         for i, p in enumerate(params):
             p.grad = torch.from_numpy(z["g%d_%d" % (s, i)].astype(np.float32)).to(DEV)
         if fused_clip:
-            opt.step(clip_grad=20)
+            # default: gradients rescaled in memory like the reference's clip_grad_norm_; "consumed": coefficient folded
+            # into the update, gradients left as they were (callers that zero them before the next backward)
+            before = [p.grad.clone() for p in params]
+            opt.step(clip_grad=20, grads_consumed=(fused_clip == "consumed"))
             total = opt.last_total_norm
+            if s == 1:
+                for i, p in enumerate(params):
+                    if fused_clip == "consumed":
+                        assert torch.equal(p.grad, before[i])
+                    else:
+                        np.testing.assert_allclose(p.grad.cpu().numpy(), z["gclip1_%d" % i], rtol=2e-6, atol=0)
         else:
             total = clip_grad_norm_(params + [frozen], 20)
             if s == 1:
@@ -155,3 +164,131 @@ def test_checkpoint_roundtrip_reference_layout(tmp_path):
         b1, b2 = opt.state.get(p1, {}).get("momentum_buffer"), opt2.state.get(p2, {}).get("momentum_buffer")
         assert (b1 is None and b2 is None) or torch.equal(b1, b2), n1
     assert opt2.param_groups[0]["lr"] == 0.01 and opt2.param_groups[0]["momentum"] == 0.9
+
+
+def _reference_loop(params, micro_grads, k, clip, lr, mom, wd):
+    """core/tools/train.py:66-94 driven by torch's own clip_grad_norm_ + optim.SGD on CPU copies: `micro_grads[it]` is what
+    iteration it's backward adds to .grad.  -> per iteration (parameters, momentum buffers, total norm)"""
+    ps = [torch.nn.Parameter(p.clone()) for p in params]
+    opt = torch.optim.SGD(ps, lr, momentum=mom, weight_decay=wd)
+    trace = []
+    for it, gs in enumerate(micro_grads):
+        if (it + 1) % k == 0:
+            opt.zero_grad()
+        for p, g in zip(ps, gs):
+            if g is not None:
+                p.grad = g.clone() if p.grad is None else p.grad + g
+        tn = torch.nn.utils.clip_grad_norm_(ps, clip) if clip else None
+        if (it + 1) % k == k - 1:
+            opt.step()
+        trace.append(([p.detach().clone() for p in ps], [opt.state[p].get("momentum_buffer") for p in ps],
+                      None if tn is None else float(tn)))
+    return trace
+
+
+@pytest.mark.parametrize("k,clip", [(2, 2.0), (3, 2.0), (2, None), (1, 2.0)])
+def test_accumulation_schedule_on_the_real_model(k, clip):
+    """SURVEY 8 f2 "accumulation semantics" (reference core/tools/train.py:66-94: zero_grad when (it+1) % k == 0 BEFORE the
+    forward, loss / k, clip_grad_norm_ on the ACCUMULATED gradients every iteration, step when (it+1) % k == k-1).
+    `TrainStep` + `FusedSGD` + the multi-tensor clip run five iterations of the small three-modality TBN model on the GPU;
+    the micro-batch gradient of every iteration is captured by tensor hooks and the reference loop is REPLAYED on the CPU
+    with torch's own `clip_grad_norm_` + `optim.SGD` on exactly those gradients: parameters, momentum buffers and the
+    clip norms agree after every iteration within 2e-6 (the schedule, the re-clipping of accumulated gradients and the
+    fused / in-place clip modes -- independent of the backbone's fp32 gradient conditioning)."""
+    from tests.util import load_case
+    from tests.test_model_gpu import build_product, to_dev
+    from attention_based_tbn_amd.core.utils import FusedSGD, TrainStep
+    cfg, modality, meta, data, inp, target = load_case("train_cfg4_all_noattn")
+    model, crit = build_product(cfg, modality, meta)
+    model.train()
+    named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+    params = [p for _, p in named]
+    p0 = [p.detach().cpu().clone() for p in params]
+    lr, mom, wd = 0.01, 0.9, 0.0005
+    opt = FusedSGD(params, lr, momentum=mom, weight_decay=wd)
+    step = TrainStep(model, opt, crit, accumulator_step=k, clip_grad=clip)
+    micro = []
+    hooks = [p.register_hook(lambda g, i=i: micro[-1].__setitem__(i, g.detach().cpu().clone())) for i, p in enumerate(params)]
+    g = torch.Generator().manual_seed(k)
+    got = []
+    for it in range(5):
+        micro.append([None] * len(params))
+        x = {m: v + 0.05 * torch.randn(v.shape, generator=g) for m, v in inp.items()}
+        loss, bs = step(it, to_dev(x), {"class": to_dev(target["class"])}, epoch=0)
+        assert bs == 2
+        got.append(([p.detach().cpu().clone() for p in params],
+                    [opt.state[p].get("momentum_buffer") for p in params],
+                    None if step.last_total_norm is None else float(step.last_total_norm)))
+        got[-1] = (got[-1][0], [None if b is None else b.cpu().clone() for b in got[-1][1]], got[-1][2])
+    for h in hooks:
+        h.remove()
+    want = _reference_loop(p0, micro, k, clip, lr, mom, wd)
+    nclipped = 0
+    for it in range(5):
+        gp, gm, gn = got[it]
+        wp, wm, wn = want[it]
+        if clip:
+            assert abs(gn - wn) <= 4e-6 * wn, (it, gn, wn)
+            nclipped += int(wn > clip)
+        for (n, _), a, b, ma, mb in zip(named, gp, wp, gm, wm):
+            np.testing.assert_allclose(a.numpy(), b.numpy(), rtol=2e-6, atol=2e-7, err_msg=f"it {it} {n}")
+            assert (ma is None) == (mb is None), (it, n)
+            if ma is not None:
+                np.testing.assert_allclose(ma.numpy(), mb.numpy(), rtol=4e-6, atol=2e-7, err_msg=f"it {it} momentum {n}")
+    assert not clip or nclipped >= 3, nclipped          # the clip bit, also on re-clipped accumulated gradients
+    if k > 1:   # the first optimiser step of the reference schedule comes after iteration k - 2, not k - 1
+        first = min(it for it in range(5) if (it + 1) % k == k - 1)
+        assert all(torch.equal(a, b) for a, b in zip(got[first - 1][0], p0)) if first > 0 else True
+        assert not all(torch.equal(a, b) for a, b in zip(got[first][0], p0))
+
+
+def test_accumulation_k2_against_the_cpu_oracle_in_the_loop():
+    """the same schedule with the CPU ORACLE model in the loop (its own forward / backward, torch's clip_grad_norm_ and
+    optim.SGD, the reference loop body written out): four iterations at accumulator_step = 2 on the small TBN model.
+    Losses within 1e-3 every iteration; the accumulated parameter UPDATE of every tensor agrees with the oracle's as its
+    gradients do (relative L2 < 3e-2, cosine > 0.999: two fp32 runs of this graph differ by last-bit ReLU / max-pool
+    decisions, tests/test_model_gpu.py), the clip norms within 2e-2."""
+    from tests.util import build_oracle, load_case
+    from tests.test_model_gpu import build_product, to_dev
+    from attention_based_tbn_amd.core.utils import FusedSGD, TrainStep
+    cfg, modality, meta, data, inp, target = load_case("train_cfg4_all_noattn")
+    model, crit = build_product(cfg, modality, meta)
+    oracle, ocrit = build_oracle(cfg, modality, meta)
+    model.train()
+    oracle.train()
+    k, clip, lr, mom, wd = 2, 2.0, 0.01, 0.9, 0.0005
+    opt = FusedSGD([p for p in model.parameters() if p.requires_grad], lr, momentum=mom, weight_decay=wd)
+    oopt = torch.optim.SGD([p for p in oracle.parameters() if p.requires_grad], lr, momentum=mom, weight_decay=wd)
+    step = TrainStep(model, opt, crit, accumulator_step=k, clip_grad=clip)
+    p0 = {n: p.detach().clone() for n, p in oracle.named_parameters()}
+    g = torch.Generator().manual_seed(3)
+    for it in range(4):
+        x = {m: v + 0.05 * torch.randn(v.shape, generator=g) for m, v in inp.items()}
+        loss, _ = step(it, to_dev(x), {"class": to_dev(target["class"])}, epoch=0)
+        if (it + 1) % k == 0:
+            oopt.zero_grad()
+        oloss, _ = oracle.get_loss(ocrit, target, oracle({m: v.clone() for m, v in x.items()}), 0)
+        oloss["total"] = oloss["total"] / k
+        oloss["total"].backward()
+        otn = float(torch.nn.utils.clip_grad_norm_(oracle.parameters(), clip))
+        if (it + 1) % k == k - 1:
+            oopt.step()
+        a, b = float(loss["total"].detach()), float(oloss["total"].detach())
+        assert abs(a - b) <= 1e-3 * max(1.0, abs(b)), (it, a, b)
+        assert abs(float(step.last_total_norm) - otn) <= 2e-2 * otn, (it, float(step.last_total_norm), otn)
+    sd = model.state_dict()
+    worst = (0.0, "")
+    for n, q in oracle.named_parameters():
+        if not q.requires_grad:
+            continue
+        du = (sd[n].detach().cpu().double() - p0[n].double()).flatten()
+        dw = (q.detach().double() - p0[n].double()).flatten()
+        if float(dw.norm()) < 1e-12:
+            assert float(du.norm()) < 1e-9, n
+            continue
+        e = float((du - dw).norm() / dw.norm())
+        c = float(torch.dot(du, dw) / (du.norm() * dw.norm()))
+        if e > worst[0]:
+            worst = (e, n)
+        assert e < 3e-2 and c > 0.999, (n, e, c)
+    print("accumulated update vs oracle: worst relative L2 %.2e at %s" % worst)
