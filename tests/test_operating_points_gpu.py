@@ -17,7 +17,8 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from tests.util import build_oracle, rel_err  # noqa: E402
-from tests.test_model_gpu import DEV, build_product, cosine, l2_err, reference_named_grads, to_dev  # noqa: E402
+from tests.test_model_gpu import (DEV, PER_LAYER_COS, PER_LAYER_L2, build_product, cosine, l2_err,  # noqa: E402
+                                  per_layer_grad_parity, reference_named_grads, to_dev)
 
 
 def _meta(cfg, modality, fill_seed):
@@ -126,6 +127,8 @@ def test_config3_full_batch_train_step_vs_oracle(audio_length, audio_w, T):
         e = l2_err(got, want)
         print("R = 192 parity: %s conv weight gradients relative L2 %.2e, cosine %.6f" % (m, e, cosine(got, want)))
         assert e < 3e-2 and cosine(got, want) > 0.999, (m, e)
+    n_layers = per_layer_grad_parity(grads, ograds, modality, "R = 192", PER_LAYER_L2, PER_LAYER_COS)   # every layer on its own
+    assert n_layers == 2 * (69 + 2), n_layers         # per backbone: 69 conv weights + the trainable first-BN affine pair (partialbn)
     # the attention stack (positional-encoding projection, GroupNorm, MHA) and the heads: no ReLU / max-pool decisions of
     # their own, but they sit behind the backbones' -> same rule, per tensor group
     for prefix in ("pe.", "attention_layer.", "fusion.", "classifier."):
