@@ -5,6 +5,12 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libtbn_hip.so")
+if os.environ.get("TBN_LIB"):
+    # diagnostic / A-B builds (attention_based_tbn_amd/build.py, TBN_BUILD_VARIANT): loaded INSTEAD of the shipped library,
+    # never copied over it; said out loud because results of a TBN_DIAG build are invalid
+    import sys as _sys
+    LIB_PATH = os.path.abspath(os.environ["TBN_LIB"])
+    print(f"[tbn] TBN_LIB set: loading {LIB_PATH} instead of the shipped libtbn_hip.so", file=_sys.stderr)
 
 c_fp = C.c_void_p   # device pointers are passed as integers (tensor.data_ptr())
 c_i = C.c_int
@@ -68,6 +74,10 @@ SIGNATURES = {
     "tbn_backbone_tensor_info": (c_i, [C.c_void_p, C.c_char_p, c_i, C.POINTER(C.c_long), C.POINTER(c_i),
                                        C.POINTER(c_i), C.POINTER(c_i)]),
     "tbn_backbone_launch_info": (c_i, [C.c_void_p, C.c_char_p, c_i, C.POINTER(c_i)]),
+    "tbn_backbone_plan_export_bytes": (c_sz, [C.c_void_p]),
+    "tbn_backbone_plan_export": (c_i, [C.c_void_p, C.c_void_p, c_sz]),
+    "tbn_backbone_plan_import": (c_i, [C.c_void_p, C.c_void_p, c_sz]),
+    "tbn_backbone_plan_fingerprint": (C.c_ulonglong, [C.c_void_p]),
     "tbn_backbone_forward": (c_i, [C.c_void_p, c_i, c_fp, C.POINTER(BackboneParams), c_fp, c_sz,
                                    C.POINTER(C.c_void_p), c_fp]),
     "tbn_backbone_autotune": (c_i, [C.c_void_p, c_i, C.POINTER(BackboneParams), c_fp, c_sz, c_fp]),

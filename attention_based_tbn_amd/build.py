@@ -38,7 +38,17 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-STAMP = os.path.join(CSRC, ".build_flags")   # the flag set the objects were built with (diagnostic -D switches included)
+# Diagnostic / experiment builds (TBN_DIAG=1, TBN_ABLATE=1, TBN_EXTRA_FLAGS) never replace the shipped library: with
+# TBN_BUILD_VARIANT=<name> objects and library go to scripts/ab/obj_<name>/ and scripts/ab/lib_<name>.so, and a run picks the
+# variant with TBN_LIB=<path> (attention_based_tbn_amd/_lib.py) -- nothing is copied over libtbn_hip.so (round-4 advisor)
+VARIANT = os.environ.get("TBN_BUILD_VARIANT")
+OBJDIR = CSRC
+if VARIANT:
+    _ab = os.path.join(os.path.dirname(HERE), "scripts", "ab")
+    OBJDIR = os.path.join(_ab, "obj_" + VARIANT)
+    LIB = os.path.join(_ab, "lib_" + VARIANT + ".so")
+    os.makedirs(OBJDIR, exist_ok=True)
+STAMP = os.path.join(OBJDIR, ".build_flags")   # the flag set the objects were built with (diagnostic -D switches included)
 
 
 def build(force=False, verbose=True):
@@ -49,13 +59,13 @@ def build(force=False, verbose=True):
             if f.read() != flagset:
                 force = True         # e.g. a TBN_DIAG / TBN_ABLATE build before: never link those objects into a plain build
     except OSError:
-        force = force or any(os.path.exists(os.path.join(CSRC, s.replace(".hip", ".o"))) for s in SOURCES)
+        force = force or any(os.path.exists(os.path.join(OBJDIR, s.replace(".hip", ".o"))) for s in SOURCES)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.join(os.path.dirname(HERE), "include", "tbn_hip.h"))
     objs, jobs = [], []
     for s in SOURCES:
         src = os.path.join(CSRC, s)
-        obj = os.path.join(CSRC, s.replace(".hip", ".o"))
+        obj = os.path.join(OBJDIR, s.replace(".hip", ".o"))
         objs.append(obj)
         if force or _stale(obj, [src] + headers):
             jobs.append([hipcc] + FLAGS + ["-c", src, "-o", obj])

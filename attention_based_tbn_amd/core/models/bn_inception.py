@@ -65,6 +65,19 @@ class _Plan:
         self.pool.append([buf, weakref.ref(token) if token is not None else None])
         return buf
 
+    def export_choices(self):
+        """the tuned launch choices as bytes (include/tbn_hip.h: tbn_backbone_plan_export)"""
+        n = lib().tbn_backbone_plan_export_bytes(self.handle)
+        buf = C.create_string_buffer(n)
+        call("tbn_backbone_plan_export", self.handle, buf, n)
+        return buf.raw
+
+    def import_choices(self, blob):
+        call("tbn_backbone_plan_import", self.handle, C.c_char_p(bytes(blob)), len(blob))
+
+    def fingerprint(self):
+        return "%016x" % lib().tbn_backbone_plan_fingerprint(self.handle)
+
     def __del__(self):
         try:
             if self.handle:
@@ -95,13 +108,20 @@ class _BackboneFn(torch.autograd.Function):
         st = stream_ptr()
         if module.autotune and not plan.tuned[training]:
             # first use of this (shape, mode): run once so every buffer holds real data, time the tile
-            # candidates of each layer on it, then do the real forward below with the tuned plan
-            saved = (module.running_mean.clone(), module.running_var.clone())
-            call("tbn_backbone_forward", plan.handle, int(training), ptr(x), C.byref(prm), ptr(ws), ws.numel(),
-                 C.byref(feat_ptr), st)
-            call("tbn_backbone_autotune", plan.handle, int(training), C.byref(prm), ptr(ws), ws.numel(), st)
-            module.running_mean.copy_(saved[0])
-            module.running_var.copy_(saved[1])
+            # candidates of each layer on it, then do the real forward below with the tuned plan.
+            # Data parallel (`plan_sync` set by core.models.DataParallel): only rank 0 tunes; its choices travel to
+            # every replica (tbn_backbone_plan_export / _import), so that all ranks run the SAME kernels -- per-rank
+            # tuning from noisy on-box timings would let replicas differ and make the job's step the slowest plan's
+            sync = module.plan_sync
+            if sync is None or sync.is_source():
+                saved = (module.running_mean.clone(), module.running_var.clone())
+                call("tbn_backbone_forward", plan.handle, int(training), ptr(x), C.byref(prm), ptr(ws), ws.numel(),
+                     C.byref(feat_ptr), st)
+                call("tbn_backbone_autotune", plan.handle, int(training), C.byref(prm), ptr(ws), ws.numel(), st)
+                module.running_mean.copy_(saved[0])
+                module.running_var.copy_(saved[1])
+            if sync is not None:
+                plan.import_choices(sync.broadcast(plan.export_choices(), x.device))
             plan.tuned[training] = True
         call("tbn_backbone_forward", plan.handle, int(training), ptr(x), C.byref(prm), ptr(ws), ws.numel(),
              C.byref(feat_ptr), st)
@@ -180,6 +200,7 @@ class BNInception(nn.Module):
         # chain (include/tbn_hip.h, tbn_backbone_params.side_stream); pays while this backbone is the only one running
         self.use_branch_streams = True
         self._side_streams = {}
+        self.plan_sync = None       # data parallel: object with is_source() / broadcast(blob, device) (DataParallel.PlanSync)
         self._plans = OrderedDict()
         # layer table from the engine (needs the library, not a GPU)
         probe = C.c_void_p()
@@ -303,6 +324,11 @@ class BNInception(nn.Module):
         else:
             self._plans.move_to_end(key)
         return self._plans[key]
+
+    def plan_fingerprints(self):
+        """{(frames, H, W): hex fingerprint of the plan's launch choices} -- equal across the replicas of a data-parallel
+        job once `plan_sync` is set; `bench.py` prints them so that a slow box can be told from a different plan"""
+        return {k: p.fingerprint() for k, p in self._plans.items()}
 
     def _side_stream_ptr(self):
         """the side stream that goes with the current stream (0: serial program; also while a graph is being captured --

@@ -34,6 +34,26 @@ import torch.distributed as dist
 import torch.nn as nn
 
 
+class PlanSync:
+    """moves rank 0's tuned engine plans to every replica (reference nn.DataParallel replicas are identical by
+    construction, core/models/model_builder.py:73-75).  Called from inside the first forward of a new (shape, mode) on
+    every rank alike -- same shapes on every rank, so the broadcasts match up."""
+
+    def __init__(self, process_group=None, src=0):
+        self.group, self.src = process_group, src
+
+    def is_source(self):
+        return dist.get_rank(self.group) == self.src
+
+    def broadcast(self, blob, device):
+        t = torch.frombuffer(bytearray(blob), dtype=torch.uint8)
+        if dist.get_backend(self.group) == "nccl":
+            t = t.to(device)
+        dist.broadcast(t, dist.get_global_rank(self.group, self.src) if self.group is not None else self.src,
+                       group=self.group)
+        return bytes(t.cpu().numpy().tobytes())
+
+
 class DataParallel(nn.Module):
     SMALL = 1 << 18   # elements: gradients below 1 MB travel together in one flat buffer (one collective)
 
@@ -65,6 +85,11 @@ class DataParallel(nn.Module):
         if self.active:
             if broadcast_parameters:
                 self.broadcast_parameters()
+            if self.world_size > 1:
+                sync = PlanSync(process_group)
+                for m in self.module.modules():
+                    if hasattr(m, "plan_sync"):
+                        m.plan_sync = sync       # BNInception: autotune on rank 0 only, choices broadcast
             for p in self.module.parameters():
                 if p.requires_grad:
                     self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad_ready))

@@ -8,6 +8,7 @@ modality features are produced by HIP pooling kernels, fusion / classifier / att
 projections run on the fp32-MFMA GEMM, and the per-class classifiers run as ONE GEMM.
 """
 import os
+import sys
 from collections import OrderedDict
 
 import numpy as np
@@ -38,6 +39,26 @@ class _PEStack(nn.Sequential):
     def forward(self, x):
         """reference layout (R, 1024, 1, T) -> (R, 1024, T)"""
         return self.forward_sequence(x.squeeze(2).transpose(1, 2).contiguous()).transpose(1, 2)
+
+
+def _high_priority_modalities():
+    """the modalities whose backbone stream gets HIP priority -1: "Audio" (shipped).  TBN_HIGH_PRIO is an A/B knob; a value
+    that is not a comma-separated list of modality names is refused (and said so once) instead of silently changing the
+    stream priorities a run measures"""
+    raw = os.environ.get("TBN_HIGH_PRIO")
+    if raw is None:
+        return ["Audio"]
+    names = [x for x in raw.split(",") if x]
+    if any(x not in ("RGB", "Flow", "Audio", "none") for x in names):
+        if not getattr(_high_priority_modalities, "warned", False):
+            print(f"[tbn] experiment knob TBN_HIGH_PRIO={raw!r} ignored (expected RGB / Flow / Audio / none, comma separated)",
+                  file=sys.stderr)
+            _high_priority_modalities.warned = True
+        return ["Audio"]
+    if names != ["Audio"] and not getattr(_high_priority_modalities, "said", False):
+        print(f"[tbn] experiment knob TBN_HIGH_PRIO={raw} active (default Audio): not the shipped configuration", file=sys.stderr)
+        _high_priority_modalities.said = True
+    return names
 
 
 class TBNModel(nn.Module):
@@ -169,7 +190,7 @@ class TBNModel(nn.Module):
                 # the heaviest backbone (audio: 5.1 GFLOP per 256x256 frame against 4.1 / 4.6) gets the high-priority
                 # stream: it is the one that finishes last and runs alone at the end of forward and backward (same-box
                 # A/B, 3 of 3: 36.13 -> 35.92 ms per step; issuing it first instead: +-0)
-                high = os.environ.get("TBN_HIGH_PRIO", "Audio").split(",")      # (A/B knob; the shipped policy is "Audio")
+                high = _high_priority_modalities()
                 st = self._streams[m] = torch.cuda.Stream(device=first.device, priority=(-1 if m in high else 0))
             st.wait_stream(main)
             with torch.cuda.stream(st):

@@ -1,6 +1,7 @@
 // C-ABI glue: error reporting and the single-operator entry points of include/tbn_hip.h.
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "tbn_common.h"
@@ -14,6 +15,19 @@ void tbn_set_error(const char* fmt, ...) {
   va_start(ap, fmt);
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
+}
+
+int tbn_env_int(const char* name, int def, int lo, int hi) {
+  const char* e = getenv(name);
+  if (e == nullptr || *e == 0) return def;
+  char* end = nullptr;
+  const long v = strtol(e, &end, 10);
+  if (end == e || *end != 0 || v < lo || v > hi) {
+    fprintf(stderr, "[tbn] experiment knob %s=%s ignored (expected an integer in [%d, %d]); using %d\n", name, e, lo, hi, def);
+    return def;
+  }
+  if ((int)v != def) fprintf(stderr, "[tbn] experiment knob %s=%ld active (default %d): not the shipped configuration\n", name, v, def);
+  return (int)v;
 }
 
 #define TBN_TRY(expr)                \

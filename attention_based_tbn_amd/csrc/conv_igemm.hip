@@ -1808,7 +1808,7 @@ int tbn_launch_conv(ConvP p, int rowmode, int mt, int nt, hipStream_t st) {
   // longest workgroups first: a phase's K is (its taps) x Cin -- 1, 2, 2 and 4 taps for a 3x3 / stride-2 layer -- and the
   // dispatcher hands out workgroups in block order, so with the 4-tap phase LAST (parity order) its 4x longer workgroups
   // started when the others were nearly done and ran the launch's tail alone
-  static const int lpt = getenv("TBN_LPT") ? atoi(getenv("TBN_LPT")) : 1;   // A/B runs: 0 = parity order
+  static const int lpt = tbn_env_int("TBN_LPT", 1, 0, 1);   // A/B runs: 0 = parity order
   for (int a = 0; a < phases.n && lpt; ++a)
     for (int b = a + 1; b < phases.n; ++b)
       if (phases.ph[b].K > phases.ph[a].K) {
@@ -1943,7 +1943,7 @@ int tbn_launch_conv_pair(ConvP a, ConvP b, int variant, int mt, int nt, hipStrea
   // the member with the longer K loop first: its workgroups are the long ones, and the dispatcher hands out workgroups in
   // block order (a launch should not end with the long workgroups of the second member running alone)
   ConvP* ms[2] = {&a, &b};
-  static const int lpt = getenv("TBN_LPT") ? atoi(getenv("TBN_LPT")) : 1;   // A/B runs: 0 = caller's order
+  static const int lpt = tbn_env_int("TBN_LPT", 1, 0, 1);   // A/B runs: 0 = caller's order
   if (b.K > a.K && lpt) {
     ms[0] = &b;
     ms[1] = &a;
@@ -1979,7 +1979,8 @@ template <int MT, int NT, int MODE>
 static void launch_wgrad(const WgradP& p, int blocks, hipStream_t st) {
   // experiment knob (A/B runs only): unused dynamic LDS caps the workgroups per CU (the 64 x 64 tile needs 64 registers and
   // 34 KB of LDS: four per CU; each split's 54 tile x tap workgroups share an x / dy slab through the XCD's 4-MB L2)
-  static const int pad = getenv("TBN_WGRAD_LDS_PAD") ? atoi(getenv("TBN_WGRAD_LDS_PAD")) : 0;
+  // (clamped to what still launches: 64 KB of dynamic LDS minus the kernel's 34 KB of static LDS)
+  static const int pad = tbn_env_int("TBN_WGRAD_LDS_PAD", 0, 0, 64 * 1024 - 36 * 1024);
   TBN_LAUNCH((conv_wgrad_kernel<MT, NT, MODE>), dim3(blocks), dim3(256), (MT == 2 && NT == 2) ? pad : 0, st, p);
 }
 
@@ -2028,7 +2029,7 @@ void tbn_wgrad_plan(int M, int Cout, int Cin, int taps, int* mt, int* nt, int* s
   int occ = (*mt == 3 || *nt == 3 || (*mt == 5 && *nt > 1)) ? 1 : 2;   // workgroups per CU the cost model assumes
   {
     // experiment knob (A/B runs only): with VGPR-form accumulators the 64 x 64 and smaller tiles fit FOUR workgroups per CU
-    static const int occ_env = getenv("TBN_WGRAD_OCC") ? atoi(getenv("TBN_WGRAD_OCC")) : 0;
+    static const int occ_env = tbn_env_int("TBN_WGRAD_OCC", 0, 0, 8);
     if (occ_env > 0 && occ == 2) occ = occ_env;
   }
   const int slots = 256 * occ;

@@ -294,7 +294,7 @@ bool build_graph(tbn_backbone_plan* P) {
     // row runs on the bordered NHWC image when that multiplies fewer K columns (flow: 512 instead of 640; RGB / audio:
     // the same 192 / 64 -> they keep the space-to-depth form and its 16-B aligned loads)
     const int rl = (7 * cin0 + 3) / 4 * 4, krows = (7 * rl + 31) / 32 * 32;
-    static const int use_rows = getenv("TBN_STEM_ROWS") ? atoi(getenv("TBN_STEM_ROWS")) : 1;   // A/B runs: 0 = always s2d
+    static const int use_rows = tbn_env_int("TBN_STEM_ROWS", 1, 0, 1);   // A/B runs: 0 = always s2d
     if (krows < P->stem_K && use_rows) {
       const int oh = (P->H + 6 - 7) / 2 + 1, ow = (P->W + 6 - 7) / 2 + 1;
       P->stem_mode = 1;
@@ -864,6 +864,110 @@ int tbn_backbone_launch_info(const tbn_backbone_plan* P, const char* conv_name, 
   return TBN_ERR_ARG;
 }
 
+// ---- tuned launch choices as a relocatable blob (host memory): what tbn_backbone_autotune decides, nothing that depends
+// on addresses.  Layout: 8 int32 header {magic, version, in_channels, frames, H, W, number of GEMMs, ints per GEMM} followed
+// by kPlanInts int32 per GEMM in plan order.
+namespace {
+constexpr int kPlanMagic = 0x54424e50;   // "TBNP"
+constexpr int kPlanVersion = 1;
+constexpr int kPlanInts = 26;
+void plan_pack(const Conv& c, int* o) {
+  int k = 0;
+  for (int m = 0; m < 2; ++m) {
+    const Conv::FwdTune& T = c.ft[m];
+    o[k++] = T.mt; o[k++] = T.nt; o[k++] = T.stages; o[k++] = T.halo;
+    o[k++] = T.pair ? 1 : 0; o[k++] = T.p_variant; o[k++] = T.p_mt; o[k++] = T.p_nt;
+  }
+  o[k++] = c.d_mt; o[k++] = c.d_nt; o[k++] = c.d_stages; o[k++] = c.d_halo;
+  o[k++] = c.pair_dgrad ? 1 : 0; o[k++] = c.pd_variant; o[k++] = c.pd_mt; o[k++] = c.pd_nt;
+  o[k++] = c.w_mt; o[k++] = c.w_nt;
+}
+bool tile_ok(int mt, int nt) { return mt >= 1 && mt <= 2 && nt >= 1 && nt <= 4; }
+}  // namespace
+
+size_t tbn_backbone_plan_export_bytes(const tbn_backbone_plan* P) {
+  return P ? sizeof(int) * (8 + (size_t)kPlanInts * P->convs.size()) : 0;
+}
+
+int tbn_backbone_plan_export(const tbn_backbone_plan* P, void* buf, size_t bytes) {
+  TBN_REQUIRE(P && buf, "plan_export: null argument");
+  TBN_REQUIRE(bytes >= tbn_backbone_plan_export_bytes(P), "plan_export: buffer too small (%zu < %zu bytes)", bytes,
+              tbn_backbone_plan_export_bytes(P));
+  int* o = (int*)buf;
+  const int hdr[8] = {kPlanMagic, kPlanVersion, P->cin0, P->frames, P->H, P->W, (int)P->convs.size(), kPlanInts};
+  memcpy(o, hdr, sizeof(hdr));
+  for (size_t i = 0; i < P->convs.size(); ++i) plan_pack(P->convs[i], o + 8 + kPlanInts * i);
+  return TBN_OK;
+}
+
+// Adopts the launch choices of a blob written by tbn_backbone_plan_export for the SAME problem (input channels, frames,
+// H, W): every replica of a data-parallel job then runs the kernels rank 0 tuned (the reference's nn.DataParallel
+// replicas are identical by construction, core/models/model_builder.py:73-75).  Every field is validated against what the
+// launchers accept; a blob that fails leaves the plan untouched.
+int tbn_backbone_plan_import(tbn_backbone_plan* P, const void* buf, size_t bytes) {
+  TBN_REQUIRE(P && buf, "plan_import: null argument");
+  TBN_REQUIRE(bytes >= sizeof(int) * 8, "plan_import: truncated blob (%zu bytes)", bytes);
+  const int* in = (const int*)buf;
+  TBN_REQUIRE(in[0] == kPlanMagic && in[1] == kPlanVersion, "plan_import: not a plan blob of this library (magic %08x, version %d)",
+              in[0], in[1]);
+  TBN_REQUIRE(in[2] == P->cin0 && in[3] == P->frames && in[4] == P->H && in[5] == P->W,
+              "plan_import: blob is for (C=%d, frames=%d, %dx%d), this plan for (C=%d, frames=%d, %dx%d)", in[2], in[3], in[4],
+              in[5], P->cin0, P->frames, P->H, P->W);
+  TBN_REQUIRE(in[6] == (int)P->convs.size() && in[7] == kPlanInts && bytes >= tbn_backbone_plan_export_bytes(P),
+              "plan_import: blob holds %d GEMMs x %d ints (%zu bytes), expected %zu x %d", in[6], in[7], bytes, P->convs.size(),
+              kPlanInts);
+  for (size_t i = 0; i < P->convs.size(); ++i) {
+    const int* q = in + 8 + kPlanInts * i;
+    const Conv& c = P->convs[i];
+    bool ok = true;
+    for (int m = 0; m < 2; ++m) {
+      const int* f = q + 8 * m;
+      ok = ok && tile_ok(f[0], f[1]) && f[2] >= 0 && f[2] <= 2 && f[3] >= 0 && f[3] <= 3 && (f[4] == 0 || f[4] == 1) &&
+           f[5] >= 0 && f[5] <= 2 && tile_ok(f[6], f[7]) && f[6] <= 2 && f[7] <= 2;
+      ok = ok && !(f[4] == 1 && c.pair_next < 0);                        // a pair decision lives on a pair's first member
+      ok = ok && !(c.stem && f[3] != 0);                                 // the stem runs the packed-row kernel only
+      ok = ok && !(f[3] == 3 && (f[0] > 2 || f[1] > 2));                 // split-K tile kernel: tiles up to (2, 2)
+    }
+    const int* d = q + 16;
+    ok = ok && tile_ok(d[0], d[1]) && d[2] >= 0 && d[2] <= 2 && d[3] >= 0 && d[3] <= 3 && (d[4] == 0 || d[4] == 1) &&
+         d[5] >= 0 && d[5] <= 2 && tile_ok(d[6], d[7]) && d[6] <= 2 && d[7] <= 2;
+    ok = ok && !(d[4] == 1 && (c.pair_next < 0 || c.stride != 1));
+    ok = ok && !(d[3] == 3 && (d[0] > 2 || d[1] > 2 || c.stride != 1));
+    ok = ok && !((d[3] == 1 || d[3] == 2) && c.stride != 1);            // parity-phase launches: register-staged kernel
+    ok = ok && q[24] >= 0 && q[24] <= 5 && q[25] >= 0 && q[25] <= 5;
+    TBN_REQUIRE(ok, "plan_import: invalid launch choice for GEMM %zu (%s)", i, c.parts[c.nparts - 1].name.c_str());
+  }
+  for (size_t i = 0; i < P->convs.size(); ++i) {
+    const int* q = in + 8 + kPlanInts * i;
+    Conv& c = P->convs[i];
+    for (int m = 0; m < 2; ++m) {
+      Conv::FwdTune& T = c.ft[m];
+      const int* f = q + 8 * m;
+      T.mt = f[0]; T.nt = f[1]; T.stages = f[2]; T.halo = f[3];
+      T.pair = f[4] != 0; T.p_variant = f[5]; T.p_mt = f[6]; T.p_nt = f[7];
+    }
+    const int* d = q + 16;
+    c.d_mt = d[0]; c.d_nt = d[1]; c.d_stages = d[2]; c.d_halo = d[3];
+    c.pair_dgrad = d[4] != 0; c.pd_variant = d[5]; c.pd_mt = d[6]; c.pd_nt = d[7];
+    c.w_mt = q[24]; c.w_nt = q[25];
+  }
+  return TBN_OK;
+}
+
+// 64-bit FNV-1a over the export blob: equal fingerprints <=> equal launch choices for the same problem
+unsigned long long tbn_backbone_plan_fingerprint(const tbn_backbone_plan* P) {
+  if (!P) return 0;
+  std::vector<int> blob(8 + (size_t)kPlanInts * P->convs.size());
+  if (tbn_backbone_plan_export(P, blob.data(), blob.size() * sizeof(int)) != TBN_OK) return 0;
+  unsigned long long h = 1469598103934665603ull;
+  const unsigned char* b = (const unsigned char*)blob.data();
+  for (size_t i = 0; i < blob.size() * sizeof(int); ++i) {
+    h ^= b[i];
+    h *= 1099511628211ull;
+  }
+  return h;
+}
+
 size_t tbn_backbone_weight_floats(const tbn_backbone_plan* P) { return P->weight_floats; }
 size_t tbn_backbone_channel_floats(const tbn_backbone_plan* P) { return P->chan_floats; }
 size_t tbn_backbone_workspace_bytes(const tbn_backbone_plan* P, int training) {
@@ -1051,6 +1155,21 @@ struct AuxJoin {
   }
 };
 
+// joins the side (branch) stream into the launch stream on every exit path: a TBN_TRY / TBN_REQUIRE that returns between
+// an OP_FORK and its OP_JOIN would otherwise leave side-stream kernels reading and writing the workspace while the caller
+// (seeing the error) frees or reuses it, or enqueues on the launch stream (round-4 advisor)
+struct SideJoin {
+  hipStream_t st, side;
+  hipEvent_t ev;
+  bool open = false;   // the side chain of the current block has been forked and not yet joined
+  ~SideJoin() {
+    if (side != nullptr && open) {
+      (void)hipEventRecord(ev, side);
+      (void)hipStreamWaitEvent(st, ev, 0);
+    }
+  }
+};
+
 }  // namespace
 
 extern "C" {
@@ -1075,6 +1194,7 @@ int tbn_backbone_forward(const tbn_backbone_plan* P, int training, const float* 
   const bool br = side != nullptr;
   tbn_backbone_plan* PM = const_cast<tbn_backbone_plan*>(P);  // event pool only
   if (br) TBN_TRY(ensure_events(PM));
+  SideJoin sjoin{st, side, br ? PM->ev[tbn_backbone_plan::kEvents - 2] : nullptr};
   int ev_next = 0;
   float* mean = ws + P->stats_off;
   float* rstd = mean + P->chan_floats;
@@ -1129,6 +1249,7 @@ int tbn_backbone_forward(const tbn_backbone_plan* P, int training, const float* 
       hipEvent_t e = PM->ev[ev_next++];
       (void)hipEventRecord(e, o.kind == OP_FORK ? st_main : side);
       (void)hipStreamWaitEvent(o.kind == OP_FORK ? side : st_main, e, 0);
+      sjoin.open = o.kind == OP_FORK;
       continue;
     }
     if (o.kind == OP_CONV) {
@@ -1353,15 +1474,15 @@ int tbn_backbone_autotune(tbn_backbone_plan* P, int training, const tbn_backbone
       // way -- 0.4 % slower than the size heuristic of tbn_wgrad_plan.)
       float best = 1e30f;
       int bm = 1, bn = 1, bs = 2, bh = 0;
-      static const int force_halo = getenv("TBN_FORCE_HALO") ? atoi(getenv("TBN_FORCE_HALO")) : -1;   // tests: 0 / 1
+      static const int force_halo = tbn_env_int("TBN_FORCE_HALO", -1, -1, 1);   // tests: 0 / 1
       Cand cand[kMaxCand];
       int ncand = 0;
       for (int mt = 1; mt <= 2 && rc == TBN_OK; ++mt)
         for (int nt = 1; nt <= 4 && rc == TBN_OK; ++nt)
           for (int stg = 0; stg <= 4 && rc == TBN_OK; ++stg) {   // 0: LDS-halo kernel (3x3 / stride-1 layers), 3: LDS-DMA,
             if (32 * (nt - 1) >= p.Cout) continue;               // 4: 32-row tiles, waves split K (small maps)
-            static const int use_dma = getenv("TBN_USE_DMA") ? atoi(getenv("TBN_USE_DMA")) : 1;
-            static const int use_sk4 = getenv("TBN_USE_SK4") ? atoi(getenv("TBN_USE_SK4")) : 1;
+            static const int use_dma = tbn_env_int("TBN_USE_DMA", 1, 0, 1);
+            static const int use_sk4 = tbn_env_int("TBN_USE_SK4", 1, 0, 1);
             p.halo = stg == 0 ? 1 : (stg == 3 ? 2 : (stg == 4 ? 3 : 0));
             if (stg == 4) {
               if ((c.stem && pass == 0) || p.up != 1 || !use_sk4 || force_halo == 1 || p.M > kSk4MaxRows || mt > 2 || nt > 2)
@@ -1387,7 +1508,7 @@ int tbn_backbone_autotune(tbn_backbone_plan* P, int training, const tbn_backbone
       // HBM-bound BN kernels of the other streams.  The per-tap gather forms (register-staged / LDS-DMA) move 2-6x the
       // bytes of the LDS-halo form on a 3x3 layer (profiles/r03_pmc_traffic.json): they must beat it by a margin to win.
       // (same-box A/B of the three-stream step: margin 0 -> 36.74, 6 % -> 36.49, 15 % -> 36.53 ms; one-stream GEMM totals equal)
-      static const float halo_bias = getenv("TBN_TUNE_HALO_BIAS") ? 0.01f * (float)atof(getenv("TBN_TUNE_HALO_BIAS")) : 0.08f;
+      static const float halo_bias = 0.01f * (float)tbn_env_int("TBN_TUNE_HALO_BIAS", 8, 0, 100);
       bool any_halo = false;
       for (int k = 0; k < ncand; ++k) any_halo = any_halo || cand[k].halo == 1;
       float best_raw = 1e30f;   // the winner's MEASURED time: the traffic margin only ranks candidates, it is not a time
@@ -1425,7 +1546,7 @@ int tbn_backbone_autotune(tbn_backbone_plan* P, int training, const tbn_backbone
     if (rc != TBN_OK) break;
   }
   // sibling pairs (3x3 | double_3x3_1): one launch for both when that beats the two tuned single launches
-  static const int use_pairs = getenv("TBN_USE_PAIRS") ? atoi(getenv("TBN_USE_PAIRS")) : 1;
+  static const int use_pairs = tbn_env_int("TBN_USE_PAIRS", 1, 0, 1);
   for (size_t ci = 0; ci < P->convs.size() && rc == TBN_OK; ++ci) {
     Conv& c = P->convs[ci];
     c.ft[tr].pair = false;
@@ -1477,7 +1598,7 @@ int tbn_backbone_autotune(tbn_backbone_plan* P, int training, const tbn_backbone
           }
       }
       if (ncand > 0) (void)hipEventSynchronize(ce[2 * ncand - 1]);
-      static const float pair_halo_bias = getenv("TBN_TUNE_HALO_BIAS") ? 0.01f * (float)atof(getenv("TBN_TUNE_HALO_BIAS")) : 0.08f;
+      static const float pair_halo_bias = 0.01f * (float)tbn_env_int("TBN_TUNE_HALO_BIAS", 8, 0, 100);
       bool any_halo = false;   // cand[k].stages holds the pair variant: 0 = LDS-halo members (see the margin above)
       for (int k = 0; k < ncand; ++k) any_halo = any_halo || cand[k].stages == 0;
       float best_raw = 1e30f;
@@ -1532,11 +1653,16 @@ int tbn_backbone_backward(const tbn_backbone_plan* P, const float* dfeatures, co
   hipStream_t side = (hipStream_t)prm->side_stream;
   if (side == st || side == aux || P->ops_b.empty()) side = nullptr;
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-  const bool capturing = hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cap) != hipSuccess) {
+    (void)hipGetLastError();
+    tbn_set_error("backbone_backward: hipStreamIsCapturing failed on the launch stream (invalid stream handle?)");
+    return TBN_ERR_LAUNCH;
+  }
+  const bool capturing = cap != hipStreamCaptureStatusNone;
   if (capturing) side = nullptr;
   const bool br = side != nullptr;
   if ((aux != nullptr || br) && !capturing) TBN_TRY(ensure_events(PM));
-  TBN_REQUIRE((aux == nullptr && !br) || capturing || (PM->n_ev == NE && (int)P->convs.size() + 2 * kNumBlocks + 2 < NE),
+  TBN_REQUIRE((aux == nullptr && !br) || capturing || (PM->n_ev == NE && (int)P->convs.size() + 2 * kNumBlocks + 3 < NE),
               "backbone_backward: event pool too small");
   if (aux != nullptr) {
     // Forking the weight-gradient stream from a stream that is itself a forked member of a capture (the modality streams
@@ -1552,6 +1678,7 @@ int tbn_backbone_backward(const tbn_backbone_plan* P, const float* dfeatures, co
   // events 0..NE-2 fork (launch stream -> aux), the last one is the join: whatever path leaves this function, the aux
   // stream is joined back (a fork left open would also break hipGraph capture of a step)
   AuxJoin join{st, aux, aux != nullptr ? PM->ev[NE - 1] : nullptr};
+  SideJoin sjoin{st, side, br ? PM->ev[NE - 2] : nullptr};   // (destroyed first: the side stream joins, then the aux stream)
   int ev_next = 0;
   float* ws = (float*)workspace;
   const int R = P->frames;
@@ -1593,6 +1720,7 @@ int tbn_backbone_backward(const tbn_backbone_plan* P, const float* dfeatures, co
       hipEvent_t e = PM->ev[ev_next++];
       (void)hipEventRecord(e, fork ? st_main : side);
       (void)hipStreamWaitEvent(fork ? side : st_main, e, 0);
+      sjoin.open = fork;
       if (!fork) {
         for (int k = 0; k < ndef; ++k) TBN_TRY(issue_wgrad(P->convs[deferred[k]], st_main));
         ndef = 0;

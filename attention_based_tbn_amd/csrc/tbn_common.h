@@ -29,6 +29,11 @@ void tbn_set_error(const char* fmt, ...);
     }                                                                              \
   } while (0)
 
+// A/B experiment knobs (environment variables read by shipped code): validated ONCE -- a value outside [lo, hi] or not a
+// number is refused (the default is used) and every knob that is set is announced on stderr, so a stray variable can
+// neither make every launch fail nor silently change the kernels a run measures (round-4 advisor).
+int tbn_env_int(const char* name, int def, int lo, int hi);
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 

@@ -130,6 +130,17 @@ int tbn_backbone_tensor_info(const tbn_backbone_plan* plan, const char* conv_nam
  * 3 split-K tile), M tile, N tile, LDS stages, issued as a sibling pair (0 / 1; on the pair's first member), pair variant,
  * pair M tile, pair N tile; out[8..15] = the same for the data gradient (zeros when the layer has none / training == 0). */
 int tbn_backbone_launch_info(const tbn_backbone_plan* plan, const char* conv_name, int training, int* out16);
+/* The tuned launch choices of a plan as a relocatable blob in HOST memory (what tbn_backbone_autotune decides: per GEMM the
+ * forward choice per mode, the data-gradient choice, sibling pairing, the weight-gradient tile -- no addresses), so that a
+ * plan tuned once can be moved between processes: `DataParallel` broadcasts rank 0's blobs and every replica runs the same
+ * kernels, as the reference's nn.DataParallel replicas do by construction (core/models/model_builder.py:73-75,
+ * core/models/dataparallel.py:4-6).  export_bytes is a function of the plan's problem only; import validates the header
+ * (same in_channels / frames / H / W) and every field against what the launchers accept, and leaves the plan untouched
+ * when it refuses.  fingerprint = 64-bit FNV-1a of the blob (bench.py prints it per backbone). */
+size_t tbn_backbone_plan_export_bytes(const tbn_backbone_plan* plan);
+int tbn_backbone_plan_export(const tbn_backbone_plan* plan, void* buf, size_t bytes);
+int tbn_backbone_plan_import(tbn_backbone_plan* plan, const void* buf, size_t bytes);
+unsigned long long tbn_backbone_plan_fingerprint(const tbn_backbone_plan* plan);
 /* x_nchw: (frames, in_channels, H, W) contiguous, as the reference passes it (model.py:213).
  * training=1: batch-statistics BN, keeps activations in the workspace for backward, updates
  * running stats; training=0: running-stat BN folded into the conv epilogue.

@@ -141,7 +141,8 @@ def main_raw(argv):
                    "pattern with the bytes per request CALIBRATED on launches of known byte counts (`calibration`, "
                    "scripts/pmc_calibrate.py); writes = WRITE_SIZE (separate pass); per launch over the TIMED steps of bench.py "
                    f"--steps 3 --warmup 2 --profile-every 1 (B=32; the first {skip} steps are filtered out)" + (" | " + note if note else ""),
-           "source_sha16": source_hash(), "calibration": cal, "total_hbm_bytes_all_launches": tot, "kernels": out}
+           "source_sha16": source_hash(), "workload": os.environ.get("TBN_PMC_WORKLOAD", "config4_B32"),
+           "calibration": cal, "total_hbm_bytes_all_launches": tot, "kernels": out}
     with open(out_path, "w") as f:
         json.dump(res, f, indent=1)
     print(json.dumps(cal, indent=1))
@@ -171,6 +172,7 @@ def main():
                    f"(B=32; the first {skip} steps -- priming with autotune + warm-up -- are filtered out)"
                    + (" | " + sys.argv[5] if len(sys.argv) > 5 else ""),
            "source_sha16": source_hash(),   # sha256 over KERNEL_SOURCES of the tree the counters were collected from
+           "workload": os.environ.get("TBN_PMC_WORKLOAD", "config4_B32"),   # bench.py only quotes these figures on that workload
            "total_hbm_bytes_all_launches": tot, "kernels": out}
     with open(sys.argv[3], "w") as f:
         json.dump(res, f, indent=1)

@@ -1,9 +1,17 @@
-"""Timeline of ONE training step from a rocprofv3 --kernel-trace CSV of `bench.py --profile-every 0`:
-where the wall time of the multi-stream step goes.  Usage: step_timeline.py <kernel_trace.csv> [step_from_end=2]
+"""Timeline of ONE training step from a rocprofv3 --kernel-trace CSV of `bench.py --profile-steps 0`:
+where the wall time of the (multi-stream) step goes, per kernel family ON THE CRITICAL PATH vs HIDDEN.
 
-Steps are delimited by the fused optimiser launches (`opt_sgd_kernel`) that end each step.  Reported: wall time,
-device-idle gaps, the phases (forward / heads + loss / backward / optimiser) by first / last kernel of each kind, and
-per kernel family the summed duration and the time during which ONLY that family was running (exposed time).
+Usage: step_timeline.py <kernel_trace.csv> [step_from_end=2]
+
+Steps are delimited by the fused optimiser launches (`opt_sgd_kernel`) that end each step.  The step's wall time is
+partitioned into
+    (a) time during which at least one conv GEMM runs                      -> the MFMA-bound floor is being worked on
+    (b) time during which kernels run but NO conv GEMM                     -> exposed non-GEMM time, charged to the
+        families running then (split evenly when several run)
+    (c) device idle (no kernel of the step running: launch gaps, dependency waits)
+and per family: launches, summed duration, the part that ran UNDER a GEMM ("hidden"), the part that ran with no GEMM
+beside it ("exposed" = its share of (b)), and the time it was the ONLY family running.  A family's exposed time is what
+the step would lose at best if that family were free; hidden time costs only through contention.
 """
 import csv
 import sys
@@ -34,11 +42,16 @@ def family(name):
     n = name.replace("void ", "")
     for key, fam in (("conv_wgrad", "gemm"), ("conv_igemm", "gemm"), ("conv_halo", "gemm"), ("conv_dma", "gemm"),
                      ("conv_pair", "gemm"), ("conv_sk4", "gemm"), ("splitk_reduce", "splitk_reduce"), ("weight_flip", "weight_flip"),
-                     ("bn_bwd", "bn_backward"), ("bn_", "bn_forward"), ("maxpool", "pool"), ("avgpool", "pool"),
-                     ("pool", "pool"), ("opt_sgd", "optimizer"), ("clip", "optimizer"), ("sqnorm", "optimizer"),
-                     ("nchw_to_s2d", "layout"), ("pack_stem", "layout"), ("unpack_stem", "layout"),
-                     ("spatial_mean", "heads"), ("Cijk", "heads"), ("gemm", "heads"), ("elementwise", "torch_ew"),
-                     ("reduce_kernel", "torch_ew"), ("ncclDevKernel", "rccl")):
+                     ("bn_bwd_reduce_pooled", "bn_bwd_stem_pooled"), ("bn_bwd_apply_pooled", "bn_bwd_stem_pooled"),
+                     ("bn_apply_maxpool", "bn_fwd_stem_pooled"),
+                     ("bn_bwd_finalize", "bn_bwd_finalize"), ("bn_bwd_reduce", "bn_bwd_reduce"), ("bn_bwd_apply", "bn_bwd_apply"),
+                     ("bn_finalize", "bn_fwd_finalize"), ("bn_apply", "bn_fwd_apply"), ("bn_stats", "bn_fwd_stats"),
+                     ("bn_", "bn_other"), ("maxpool", "pool"), ("avgpool", "pool"),
+                     ("pool", "pool"), ("opt_sgd", "optimizer"), ("opt_", "optimizer"), ("clip", "optimizer"), ("sqnorm", "optimizer"),
+                     ("nchw_to_", "layout"), ("pack_stem", "layout"), ("unpack_stem", "layout"),
+                     ("spatial_mean", "heads"), ("segment_mean", "heads"), ("mul_mask", "heads"), ("Cijk", "heads"),
+                     ("gemm", "heads"), ("elementwise", "torch_ew"), ("CatArray", "torch_ew"), ("softmax", "torch_ew"),
+                     ("nll_loss", "torch_ew"), ("reduce_kernel", "torch_ew"), ("ncclDevKernel", "rccl")):
         if key in n:
             return fam
     return "other:" + n.split("<")[0].split("(")[0][:40]
@@ -51,18 +64,28 @@ for s, e, n, q in step:
     events.append((e, -1, fam))
 events.sort()
 active = defaultdict(int)
-busy = 0
-excl = defaultdict(int)
-gaps = 0
+gemm_time = nogemm_time = gaps = 0
+alone = defaultdict(float)
+hidden = defaultdict(float)
+exposed = defaultdict(float)
 last = t0
 for t, d, fam in events:
+    dt = t - last
     live = [k for k, v in active.items() if v > 0]
-    if live:
-        busy += t - last
+    if dt > 0:
+        if not live:
+            gaps += dt
+        elif "gemm" in live:
+            gemm_time += dt
+            for k in live:
+                if k != "gemm":
+                    hidden[k] += dt
+        else:
+            nogemm_time += dt
+            for k in live:
+                exposed[k] += dt / len(live)
         if len(live) == 1:
-            excl[live[0]] += t - last
-    else:
-        gaps += t - last
+            alone[live[0]] += dt
     active[fam] += d
     last = t
 tot = defaultdict(int)
@@ -70,14 +93,19 @@ cnt = defaultdict(int)
 for s, e, n, q in step:
     tot[family(n)] += e - s
     cnt[family(n)] += 1
+wall = t1 - t0
 print("step wall %.3f ms (first kernel -> last kernel end), to next step start %.3f ms, %d kernels" %
-      ((t1 - t0) / 1e6, (t_next - t0) / 1e6, len(step)))
-print("device idle inside the step %.3f ms, gap to the next step %.3f ms" % (gaps / 1e6, (t_next - t1) / 1e6))
+      (wall / 1e6, (t_next - t0) / 1e6, len(step)))
+print("partition of the wall time: >= 1 conv GEMM running %.3f ms (%.1f %%) | kernels but no GEMM %.3f ms (%.1f %%) | "
+      "device idle %.3f ms (%.1f %%); gap to the next step %.3f ms" %
+      (gemm_time / 1e6, 100.0 * gemm_time / wall, nogemm_time / 1e6, 100.0 * nogemm_time / wall, gaps / 1e6,
+       100.0 * gaps / wall, (t_next - t1) / 1e6))
 first_bwd = min((r[0] for r in step if "wgrad" in r[2] or "bn_bwd" in r[2]), default=t1)
 last_fwd_gemm = max((r[1] for r in step if r[0] < first_bwd and family(r[2]) == "gemm"), default=t0)
-last_bwd = max((r[1] for r in step if family(r[2]) in ("gemm", "bn_backward", "splitk_reduce", "layout")), default=t1)
+last_bwd = max((r[1] for r in step if family(r[2]) in ("gemm", "bn_bwd_apply", "bn_bwd_stem_pooled", "splitk_reduce", "layout")), default=t1)
 print("phases: backbone forward %.3f ms | heads + loss (fwd+bwd) %.3f ms | backbone backward %.3f ms | tail (optimiser ...) %.3f ms"
       % ((last_fwd_gemm - t0) / 1e6, (first_bwd - last_fwd_gemm) / 1e6, (last_bwd - first_bwd) / 1e6, (t1 - last_bwd) / 1e6))
-print("%-28s %8s %10s %12s" % ("family", "kernels", "sum ms", "exposed ms"))
+print("%-22s %8s %10s %12s %12s %10s" % ("family", "kernels", "sum ms", "hidden ms", "exposed ms", "alone ms"))
 for fam in sorted(tot, key=lambda k: -tot[k]):
-    print("%-28s %8d %10.3f %12.3f" % (fam, cnt[fam], tot[fam] / 1e6, excl[fam] / 1e6))
+    print("%-22s %8d %10.3f %12.3f %12.3f %10.3f" % (fam, cnt[fam], tot[fam] / 1e6, hidden[fam] / 1e6, exposed[fam] / 1e6,
+                                                     alone[fam] / 1e6))

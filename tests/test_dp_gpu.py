@@ -52,6 +52,13 @@ for k, gl in local.items():
     err = float((synced[k] - want).abs().max() / (want.abs().max() + 1e-20))
     assert err < 1e-5, (k, err)
 assert len(local) >= 12 and model._fired == set() and model._pending == []
+# every replica runs the kernels rank 0 tuned (tbn_backbone_plan_export / _import through DataParallel's PlanSync): the
+# plans' fingerprints are equal across the ranks, although each rank would have tuned from its own noisy timings
+fps = {m: getattr(model.module, "Base_" + m).plan_fingerprints() for m in modality}
+both = [None, None]
+dist.all_gather_object(both, fps)
+assert both[0] == both[1] and all(len(v) == 1 for v in fps.values()), both
+assert all(getattr(model.module, "Base_" + m).plan_sync is not None for m in modality)
 
 # ---- audio dropout (reference model.py:215-222: a per-replica host draw): the ranks exchange the draw after forward on
 # a side stream; all kept / one dropped / both dropped must give the mean of the local gradients (zeros where dropped),

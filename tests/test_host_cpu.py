@@ -484,6 +484,84 @@ def test_launch_info_reports_the_plan_choices_per_mode():
     L.tbn_backbone_plan_destroy(h)
 
 
+def test_plan_export_import_round_trip_and_fingerprint():
+    """tbn_backbone_plan_export / _import / _fingerprint on the host (no GPU): a blob moves every launch choice of a plan
+    into another plan of the same problem (fingerprints and launch_info become equal), a modified choice changes the
+    fingerprint, and blobs for another problem, truncated blobs and out-of-range choices are refused with the plan left
+    untouched.  This is what `DataParallel` broadcasts from rank 0 so that every replica runs the same kernels."""
+    import ctypes as C
+    import struct
+    from attention_based_tbn_amd._lib import lib
+    L = lib()
+    a, b, other = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    assert L.tbn_backbone_plan_create(3, 4, 96, 96, C.byref(a)) == 0
+    assert L.tbn_backbone_plan_create(3, 4, 96, 96, C.byref(b)) == 0
+    assert L.tbn_backbone_plan_create(3, 5, 96, 96, C.byref(other)) == 0
+    n = L.tbn_backbone_plan_export_bytes(a)
+    assert n == 4 * (8 + 26 * 44) and n == L.tbn_backbone_plan_export_bytes(b)        # 44 GEMMs per backbone
+    buf = C.create_string_buffer(n)
+    assert L.tbn_backbone_plan_export(a, buf, n) == 0
+    assert L.tbn_backbone_plan_export(a, buf, n - 4) < 0 and b"too small" in L.tbn_last_error()
+    fp0 = L.tbn_backbone_plan_fingerprint(a)
+    assert fp0 != 0 and fp0 == L.tbn_backbone_plan_fingerprint(b) and fp0 != L.tbn_backbone_plan_fingerprint(other)
+    ints = list(struct.unpack("%di" % (n // 4), buf.raw))
+    assert ints[:8] == [0x54424E50, 1, 3, 4, 96, 96, 44, 26]
+    # "tune" the blob by hand: the forward (training mode) and data-gradient choices of inception_4a_3x3 (a 3x3 / stride-1
+    # layer, first member of a sibling pair): LDS-halo <2,1>, paired forward launch, split-K data gradient
+    names, info = [], (C.c_int * 16)()
+    from attention_based_tbn_amd.core.models.bn_inception import BNInception
+    target = None
+    for g in range(44):
+        q = ints[8 + 26 * g: 8 + 26 * (g + 1)]
+        assert len(q) == 26
+    # find the GEMM whose training-mode forward matches launch_info of the layer, by changing one and reading it back
+    for g in range(44):
+        trial = list(ints)
+        base = 8 + 26 * g
+        trial[base + 8:base + 12] = [2, 1, 0, 1]            # training-mode forward: mt, nt, stages, variant = LDS-halo
+        blob = struct.pack("%di" % len(trial), *trial)
+        rc = L.tbn_backbone_plan_import(b, blob, len(blob))
+        if rc != 0:                                          # the stem refuses a non-generic variant: plan untouched
+            assert b"invalid launch choice" in L.tbn_last_error() and L.tbn_backbone_plan_fingerprint(b) == fp0
+            continue
+        assert L.tbn_backbone_launch_info(b, b"inception_4a_3x3", 1, info) == 0
+        if list(info)[:4] == [1, 2, 1, 0]:
+            target = g
+        assert L.tbn_backbone_plan_import(b, buf, n) == 0 and L.tbn_backbone_plan_fingerprint(b) == fp0
+    assert target is not None
+    tuned = list(ints)
+    base = 8 + 26 * target
+    tuned[base + 8:base + 16] = [2, 1, 0, 1, 1, 0, 1, 2]     # forward (training): halo <2,1>, paired (variant 0, <1,2>)
+    tuned[base + 16:base + 24] = [1, 2, 1, 3, 0, 1, 1, 1]    # data gradient: split-K tile <1,2>
+    tuned[base + 24:base + 26] = [3, 2]                      # weight-gradient tile
+    blob = struct.pack("%di" % len(tuned), *tuned)
+    assert L.tbn_backbone_plan_import(b, blob, len(blob)) == 0
+    fp1 = L.tbn_backbone_plan_fingerprint(b)
+    assert fp1 != fp0
+    assert L.tbn_backbone_launch_info(b, b"inception_4a_3x3", 1, info) == 0
+    assert list(info) == [1, 2, 1, 0, 1, 0, 1, 2, 3, 1, 2, 1, 0, 1, 1, 1]
+    assert L.tbn_backbone_launch_info(b, b"inception_4a_3x3", 0, info) == 0 and list(info)[0] == 0   # eval choices untouched
+    # ... and on to a third plan through export: a -> equal to b
+    out = C.create_string_buffer(n)
+    assert L.tbn_backbone_plan_export(b, out, n) == 0 and out.raw == blob
+    assert L.tbn_backbone_plan_import(a, out, n) == 0 and L.tbn_backbone_plan_fingerprint(a) == fp1
+    # refusals leave the plan as it was
+    assert L.tbn_backbone_plan_import(other, out, n) < 0 and b"this plan for" in L.tbn_last_error()
+    assert L.tbn_backbone_plan_import(a, out, 16) < 0 and b"truncated" in L.tbn_last_error()
+    bad = list(tuned)
+    bad[0] = 7
+    bb = struct.pack("%di" % len(bad), *bad)
+    assert L.tbn_backbone_plan_import(a, bb, len(bb)) < 0 and b"not a plan blob" in L.tbn_last_error()
+    for off, val in ((8, 3), (9, 5), (11, 4), (16, 0), (24, 9)):       # tile / variant / wgrad tile out of range
+        bad = list(tuned)
+        bad[base + off] = val
+        bb = struct.pack("%di" % len(bad), *bad)
+        assert L.tbn_backbone_plan_import(a, bb, len(bb)) < 0 and b"invalid launch choice" in L.tbn_last_error(), (off, val)
+        assert L.tbn_backbone_plan_fingerprint(a) == fp1
+    for h in (a, b, other):
+        L.tbn_backbone_plan_destroy(h)
+
+
 def test_isa_wait_scan_flags_a_wait_right_behind_its_load(tmp_path, capsys):
     """scripts/isa_wait_scan.py on a synthetic listing: a loop that waits vmcnt(0) two MFMAs behind a load is reported as
     tight, the same loop with the load issued a whole trip earlier (vmcnt(1)) is not"""

@@ -211,7 +211,7 @@ def per_layer_grad_parity(grads, ograds, modality, tag, l2_bound, cos_bound):
     and cosine; the worst five are printed.  Conv biases sit in front of a batch-statistics BN: their gradient is
     analytically zero, the product returns exact zeros and the oracle fp32 rounding noise -- compared as absolute values
     against the scale of the layer's BN-bias gradient.  Returns the number of tensors compared."""
-    rows = []
+    rows, bias_bad = [], []
     for m in modality:
         keys = [k for k in sorted(grads) if k.startswith(f"Base_{m}.")]
         assert keys and set(keys) <= set(ograds), (m, set(keys) - set(ograds))
@@ -219,8 +219,11 @@ def per_layer_grad_parity(grads, ograds, modality, tag, l2_bound, cos_bound):
             got, want = grads[k].detach().cpu(), ograds[k].detach()
             assert got.shape == want.shape, k
             if k.endswith(".bias") and "_bn." not in k:
-                ref = float(ograds[k.replace(".bias", "_bn.bias")].abs().max()) if k.replace(".bias", "_bn.bias") in ograds else 1.0
-                assert float(got.abs().max()) == 0.0 and float(want.abs().max()) <= 1e-4 * max(ref, 1e-6), (k, float(want.abs().max()))
+                # exact zeros here; the oracle holds the rounding noise of its sums (observed <= 6e-6 on conv1): judged
+                # against the size of the same layer's weight gradient
+                ref = float(ograds[k.replace(".bias", ".weight")].abs().max())
+                if not (float(got.abs().max()) == 0.0 and float(want.abs().max()) <= 1e-3 * max(ref, 1e-6)):
+                    bias_bad.append((k, float(got.abs().max()), float(want.abs().max()), ref))
                 continue
             rows.append((l2_err(got, want), cosine(got, want), k))
     rows.sort(reverse=True)
@@ -228,6 +231,7 @@ def per_layer_grad_parity(grads, ograds, modality, tag, l2_bound, cos_bound):
         print("%s per-layer parity: %-55s relative L2 %.2e  cosine %.6f" % (tag, k, e, c))
     bad = [(k, e, c) for e, c, k in rows if not (e < l2_bound and c > cos_bound)]
     assert not bad, bad[:8]
+    assert not bias_bad, bias_bad[:8]
     return len(rows)
 
 
