@@ -25,7 +25,7 @@ class ConvInfo(C.Structure):
 
 class BackboneParams(C.Structure):
     _fields_ = [("weight", c_fp), ("bias", c_fp), ("gamma", c_fp), ("beta", c_fp), ("running_mean", c_fp),
-                ("running_var", c_fp), ("momentum", c_f), ("eps", c_f), ("side_stream", c_fp)]
+                ("running_var", c_fp), ("momentum", c_f), ("eps", c_f), ("side_stream", c_fp), ("flags", c_i)]
 
 
 class BackboneGrads(C.Structure):
@@ -61,6 +61,8 @@ SIGNATURES = {
     "tbn_profile_entry": (c_i, [c_i, C.c_char_p, c_i, C.POINTER(C.c_long), C.POINTER(C.c_double),
                                 C.POINTER(C.c_double)]),
     "tbn_profile_entry_bytes": (c_i, [c_i, C.POINTER(C.c_double)]),
+    "tbn_timeline_enable": (c_i, [c_i]),
+    "tbn_timeline_dump": (c_i, [C.c_char_p]),
     "tbn_diag_mfma_burst": (c_i, [c_fp, c_i, c_i, C.POINTER(C.c_double), c_fp]),
     "tbn_backbone_plan_create": (c_i, [c_i, c_i, c_i, c_i, C.POINTER(C.c_void_p)]),
     "tbn_backbone_plan_destroy": (None, [C.c_void_p]),
@@ -71,6 +73,7 @@ SIGNATURES = {
     "tbn_backbone_workspace_bytes": (c_sz, [C.c_void_p, c_i]),
     "tbn_backbone_out_shape": (c_i, [C.c_void_p, C.POINTER(c_i), C.POINTER(c_i), C.POINTER(c_i)]),
     "tbn_backbone_num_streams": (c_i, [C.c_void_p]),
+    "tbn_backbone_rider_launches": (c_i, [C.c_void_p, C.POINTER(c_i), C.POINTER(c_i)]),
     "tbn_backbone_tensor_info": (c_i, [C.c_void_p, C.c_char_p, c_i, C.POINTER(C.c_long), C.POINTER(c_i),
                                        C.POINTER(c_i), C.POINTER(c_i)]),
     "tbn_backbone_launch_info": (c_i, [C.c_void_p, C.c_char_p, c_i, C.POINTER(c_i)]),

@@ -103,7 +103,7 @@ class _BackboneFn(torch.autograd.Function):
         gamma = torch.cat([g0, g1]) if g1.numel() else g0
         beta = torch.cat([b0, b1]) if b1.numel() else b0
         prm = BackboneParams(ptr(weight), ptr(bias), ptr(gamma), ptr(beta), ptr(module.running_mean),
-                             ptr(module.running_var), 0.1, 1e-5, module._side_stream_ptr())
+                             ptr(module.running_var), 0.1, 1e-5, module._side_stream_ptr(), module._engine_flags())
         feat_ptr = C.c_void_p()
         st = stream_ptr()
         if module.autotune and not plan.tuned[training]:
@@ -161,7 +161,7 @@ class _BackboneFn(torch.autograd.Function):
         dg = torch.zeros_like(gamma) if (bn_first or bn_rest) else None
         dbe = torch.zeros_like(beta) if (bn_first or bn_rest) else None
         prm = BackboneParams(ptr(weight), ptr(bias), ptr(gamma), ptr(beta), ptr(module.running_mean),
-                             ptr(module.running_var), 0.1, 1e-5, module._side_stream_ptr())
+                             ptr(module.running_var), 0.1, 1e-5, module._side_stream_ptr(), module._engine_flags())
         aux = 0
         # inside a stream capture (torch.cuda.graph of a whole step) the weight gradients stay on the launch stream: the
         # engine refuses an aux stream there (TBN_ERR_UNSUPPORTED -- a capture that forks from an already forked stream
@@ -200,6 +200,10 @@ class BNInception(nn.Module):
         # chain (include/tbn_hip.h, tbn_backbone_params.side_stream); pays while this backbone is the only one running
         self.use_branch_streams = True
         self._side_streams = {}
+        # riders: the BN apply / BN-backward apply of a block's independent column ranges run inside the grid of a sibling
+        # GEMM launch (include/tbn_hip.h TBN_BACKBONE_RIDERS); one-chain program only -- the engine ignores the flag in
+        # branch mode -- and bit-identical to the stand-alone passes
+        self.use_riders = True
         self.plan_sync = None       # data parallel: object with is_source() / broadcast(blob, device) (DataParallel.PlanSync)
         self._plans = OrderedDict()
         # layer table from the engine (needs the library, not a GPU)
@@ -329,6 +333,9 @@ class BNInception(nn.Module):
         """{(frames, H, W): hex fingerprint of the plan's launch choices} -- equal across the replicas of a data-parallel
         job once `plan_sync` is set; `bench.py` prints them so that a slow box can be told from a different plan"""
         return {k: p.fingerprint() for k, p in self._plans.items()}
+
+    def _engine_flags(self):
+        return 1 if self.use_riders else 0      # TBN_BACKBONE_RIDERS
 
     def _side_stream_ptr(self):
         """the side stream that goes with the current stream (0: serial program; also while a graph is being captured --

@@ -137,6 +137,70 @@ void tbn_prof_begin(const char* kernel, double flops, hipStream_t st, double byt
   g_prof_recs.push_back(r);
   g_prof_open = (int)g_prof_recs.size() - 1;
 }
+bool tbn_prof_enabled() { return g_prof_on; }
+
+// ---- kernel timeline
+namespace {
+struct TlRec {
+  std::string name;
+  void* stream;
+  hipEvent_t a, b;
+};
+std::mutex g_tl_mu;
+bool g_tl_on = false;
+std::vector<TlRec> g_tl;
+}  // namespace
+bool tbn_tl_on() { return g_tl_on; }
+void tbn_tl_events(const char* name, hipStream_t st, hipEvent_t* start, hipEvent_t* stop) {
+  std::lock_guard<std::mutex> lk(g_tl_mu);
+  TlRec r;
+  r.name = name;
+  r.stream = (void*)st;
+  r.a = r.b = nullptr;
+  (void)hipEventCreate(&r.a);
+  (void)hipEventCreate(&r.b);
+  *start = r.a;
+  *stop = r.b;
+  g_tl.push_back(r);
+}
+extern "C" int tbn_timeline_enable(int on) {
+  std::lock_guard<std::mutex> lk(g_tl_mu);
+  if (on) {
+    for (auto& r : g_tl) {
+      (void)hipEventDestroy(r.a);
+      (void)hipEventDestroy(r.b);
+    }
+    g_tl.clear();
+  }
+  g_tl_on = on != 0;
+  return TBN_OK;
+}
+extern "C" int tbn_timeline_dump(const char* path) {
+  TBN_REQUIRE(path != nullptr, "timeline_dump: null path");
+  (void)hipDeviceSynchronize();
+  std::lock_guard<std::mutex> lk(g_tl_mu);
+  FILE* f = fopen(path, "w");
+  TBN_REQUIRE(f != nullptr, "timeline_dump: cannot open %s", path);
+  fprintf(f, "Kernel_Name,Queue_Id,Start_Timestamp,End_Timestamp\n");
+  if (!g_tl.empty()) {
+    // common clock: nanoseconds after the first recorded launch began (kernels of other streams may have begun earlier)
+    const hipEvent_t ref = g_tl[0].a;
+    for (auto& r : g_tl) {
+      float a = 0.f, d = 0.f;
+      if (hipEventElapsedTime(&a, ref, r.a) != hipSuccess || hipEventElapsedTime(&d, r.a, r.b) != hipSuccess) {
+        (void)hipGetLastError();
+        continue;
+      }
+      std::string nm = r.name;
+      for (auto& ch : nm)
+        if (ch == ',' || ch == '"') ch = ';';
+      const long long s0 = (long long)((double)a * 1e6) + 1000000000ll;
+      fprintf(f, "%s,%p,%lld,%lld\n", nm.c_str(), r.stream, s0, s0 + (long long)((double)d * 1e6));
+    }
+  }
+  fclose(f);
+  return TBN_OK;
+}
 bool tbn_prof_launch_events(hipEvent_t* start, hipEvent_t* stop) {
   if (!g_prof_on) return false;
   std::lock_guard<std::mutex> lk(g_prof_mu);

@@ -58,7 +58,7 @@ int tbn_bn_stats_parts(int P, int C) {
 int tbn_launch_bn_stats(const float* y, int ld, int P, int C, float* partial, int* nparts, hipStream_t st) {
   TBN_REQUIRE(C % 4 == 0 && C <= 1024 && ld % 4 == 0, "bn_stats: C must be a multiple of 4 and <= 1024");
   const int rp = 256 / (C / 4), pch = pick_chunk(P, rp), parts = cdiv(P, pch);
-  hipLaunchKernelGGL(bn_stats_kernel, dim3(parts), dim3(256), 0, st, y, ld, P, C, pch, partial);
+  TBN_KLAUNCH(bn_stats_kernel, dim3(parts), dim3(256), 0, st, y, ld, P, C, pch, partial);
   TBN_CHECK_LAUNCH("bn_stats");
   if (nparts) *nparts = parts;
   return TBN_OK;
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
 int tbn_launch_bn_finalize(const float* partial, int nparts, int P, int C, const float* gamma, const float* beta,
                            const float* conv_bias, float* running_mean, float* running_var, float momentum, float eps,
                            float* save_mean, float* save_rstd, float* scale, float* shift, hipStream_t st) {
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, TBN_FIN_CH)), dim3(256), 0, st, partial, nparts, P, C, gamma, beta,
+  TBN_KLAUNCH(bn_finalize_kernel, dim3(cdiv(C, TBN_FIN_CH)), dim3(256), 0, st, partial, nparts, P, C, gamma, beta,
                      conv_bias, running_mean, running_var, momentum, eps, save_mean, save_rstd, scale, shift);
   TBN_CHECK_LAUNCH("bn_finalize");
   return TBN_OK;
@@ -154,7 +154,7 @@ int tbn_launch_bn_apply(const float* y, int P, int C, const float* scale, const 
     TBN_REQUIRE(segs[i].ld % 4 == 0 && segs[i].col_begin % 4 == 0, "bn_apply: segment pitch/offset must be x4");
   }
   TBN_REQUIRE((size_t)P * (C / 4) < (1ull << 31), "bn_apply: too many elements per call");
-  hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid((size_t)P * C / 4)), dim3(256), 0, st, y, P, C, scale, shift, s3,
+  TBN_KLAUNCH(bn_apply_kernel, dim3(ew_grid((size_t)P * C / 4)), dim3(256), 0, st, y, P, C, scale, shift, s3,
                      make_fastdiv((uint32_t)(C / 4)));
   TBN_CHECK_LAUNCH("bn_apply");
   return TBN_OK;
@@ -175,7 +175,7 @@ __global__ void bn_fold_kernel(const float* gamma, const float* beta, const floa
 
 int tbn_launch_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var, const float* bias,
                        float eps, float* scale, float* shift, int C, hipStream_t st) {
-  hipLaunchKernelGGL(bn_fold_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, gamma, beta, mean, var, bias, eps, scale,
+  TBN_KLAUNCH(bn_fold_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, gamma, beta, mean, var, bias, eps, scale,
                      shift, C);
   TBN_CHECK_LAUNCH("bn_fold");
   return TBN_OK;
@@ -238,7 +238,7 @@ int tbn_launch_bn_apply_maxpool(const float* y, int N, int H, int W, int C, cons
   size_t g = ((size_t)N * OH * OW * (C / 4) + 255) / 256;
   if (g > 8192) g = 8192;
   TBN_REQUIRE((size_t)N * H * W * (C / 4) < (1ull << 31), "bn_apply_maxpool: too many elements per call");
-  hipLaunchKernelGGL(bn_apply_maxpool_kernel, dim3((unsigned)(g < 1 ? 1 : g)), dim3(256), 0, st, y, N, H, W, C, scale,
+  TBN_KLAUNCH(bn_apply_maxpool_kernel, dim3((unsigned)(g < 1 ? 1 : g)), dim3(256), 0, st, y, N, H, W, C, scale,
                      shift, out, out_ld, argmax, OH, OW, stride, pad, make_pixdecode(C / 4, OW, OH));
   TBN_CHECK_LAUNCH("bn_apply_maxpool");
   return TBN_OK;
@@ -385,7 +385,7 @@ int tbn_launch_bn_bwd_reduce(const CSeg* dz, int nseg, const float* y, int P, in
   TBN_REQUIRE(fill_cseg3(&s3, dz, nseg) == 0, "bn_bwd_reduce: segment pitch/offset must be x4");
   const int rp = 256 / (C / 4), pch = pick_chunk(P, rp), parts = cdiv(P, pch);
   PoolGrad none = {};
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, dim3(parts), dim3(256), 0, st, s3, none, y, P, C, pch, scale, shift,
+  TBN_KLAUNCH(bn_bwd_reduce_kernel<false>, dim3(parts), dim3(256), 0, st, s3, none, y, P, C, pch, scale, shift,
                      mean, rstd, partial);
   TBN_CHECK_LAUNCH("bn_bwd_reduce");
   return TBN_OK;
@@ -520,7 +520,7 @@ int tbn_launch_bn_bwd_reduce_pooled(const float* dpooled, int dpooled_ld, const 
   if (stride == 2 && pad == 0) {
     const int NQ = N * ((H + 1) / 2) * ((W + 1) / 2);
     const int rp = 256 / (C / 4), qch = pick_chunk(NQ, rp), parts = cdiv(NQ, qch);
-    hipLaunchKernelGGL(bn_bwd_reduce_pooled2x2_kernel, dim3(parts), dim3(256), 0, st,
+    TBN_KLAUNCH(bn_bwd_reduce_pooled2x2_kernel, dim3(parts), dim3(256), 0, st,
                        make_poolblk(dpooled, dpooled_ld, argmax, H, W, OH, OW, C), y, NQ, C, qch, scale, shift, mean, rstd,
                        partial);
     TBN_CHECK_LAUNCH("bn_bwd_reduce_pooled2x2");
@@ -530,7 +530,7 @@ int tbn_launch_bn_bwd_reduce_pooled(const float* dpooled, int dpooled_ld, const 
   CSeg3 s3 = {};
   s3.n = 1;
   const int rp = 256 / (C / 4), pch = pick_chunk(P, rp), parts = cdiv(P, pch);
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, dim3(parts), dim3(256), 0, st, s3,
+  TBN_KLAUNCH(bn_bwd_reduce_kernel<true>, dim3(parts), dim3(256), 0, st, s3,
                      make_poolgrad(dpooled, dpooled_ld, argmax, H, W, OH, OW, C, stride, pad), y, P, C, pch, scale,
                      shift, mean, rstd, partial);
   TBN_CHECK_LAUNCH("bn_bwd_reduce_pooled");
@@ -564,7 +564,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
 int tbn_launch_bn_bwd_finalize(const float* partial, int nparts, int P, int C, const float* scale, const float* mean,
                                const float* rstd, float* coef, float* dgamma, float* dbeta, float* dbias,
                                hipStream_t st) {
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, TBN_FIN_CH)), dim3(256), 0, st, partial, nparts, P, C, scale, mean,
+  TBN_KLAUNCH(bn_bwd_finalize_kernel, dim3(cdiv(C, TBN_FIN_CH)), dim3(256), 0, st, partial, nparts, P, C, scale, mean,
                      rstd, coef, dgamma, dbeta, dbias);
   TBN_CHECK_LAUNCH("bn_bwd_finalize");
   return TBN_OK;
@@ -607,7 +607,7 @@ int tbn_launch_bn_bwd_apply(const CSeg* dz, int nseg, const float* y, int P, int
   TBN_REQUIRE(C % 4 == 0 && nseg >= 1 && nseg <= 3 && fill_cseg3(&s3, dz, nseg) == 0, "bn_bwd_apply: bad segments");
   PoolGrad none = {};
   TBN_REQUIRE((size_t)P * (C / 4) < (1ull << 31), "bn_bwd_apply: too many elements per call");
-  hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(ew_grid((size_t)P * C / 4)), dim3(256), 0, st, s3, none, y, P, C,
+  TBN_KLAUNCH(bn_bwd_apply_kernel<false>, dim3(ew_grid((size_t)P * C / 4)), dim3(256), 0, st, s3, none, y, P, C,
                      scale, shift, coef, dy, make_fastdiv((uint32_t)(C / 4)));
   TBN_CHECK_LAUNCH("bn_bwd_apply");
   return TBN_OK;
@@ -620,7 +620,7 @@ int tbn_launch_bn_bwd_apply_pooled(const float* dpooled, int dpooled_ld, const u
   if (stride == 2 && pad == 0) {
     const int NQ = N * ((H + 1) / 2) * ((W + 1) / 2);
     TBN_REQUIRE((size_t)NQ * (C / 4) < (1ull << 31), "bn_bwd_apply_pooled: too many elements per call");
-    hipLaunchKernelGGL(bn_bwd_apply_pooled2x2_kernel, dim3(ew_grid((size_t)NQ * C / 4)), dim3(256), 0, st,
+    TBN_KLAUNCH(bn_bwd_apply_pooled2x2_kernel, dim3(ew_grid((size_t)NQ * C / 4)), dim3(256), 0, st,
                        make_poolblk(dpooled, dpooled_ld, argmax, H, W, OH, OW, C), y, NQ, C, scale, shift, coef, dy,
                        make_fastdiv((uint32_t)(C / 4)));
     TBN_CHECK_LAUNCH("bn_bwd_apply_pooled2x2");
@@ -629,7 +629,7 @@ int tbn_launch_bn_bwd_apply_pooled(const float* dpooled, int dpooled_ld, const u
   const int P = N * H * W;
   CSeg3 s3 = {};
   s3.n = 1;
-  hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(ew_grid((size_t)P * C / 4)), dim3(256), 0, st, s3,
+  TBN_KLAUNCH(bn_bwd_apply_kernel<true>, dim3(ew_grid((size_t)P * C / 4)), dim3(256), 0, st, s3,
                      make_poolgrad(dpooled, dpooled_ld, argmax, H, W, OH, OW, C, stride, pad), y, P, C, scale, shift,
                      coef, dy, make_fastdiv((uint32_t)(C / 4)));
   TBN_CHECK_LAUNCH("bn_bwd_apply_pooled");

@@ -8,9 +8,11 @@
 // with a scalar scan of the block-offset table and then runs the single-layer code of bn.hip on it (same
 // arithmetic, same summation order: results are bit-identical to the per-layer launches).
 #include <cstdlib>
+#include <cstring>
 #include "tbn_common.h"
 #include "tbn_kernels.h"
 #include "tbn_bn_dev.h"
+#include "tbn_rider_dev.h"
 
 namespace {
 
@@ -81,11 +83,15 @@ __global__ __launch_bounds__(256) void bn_apply_multi_kernel(BnFwdBatch b) {
   const int li = find_layer(b.app_blk0, b.n, blockIdx.x);
   const BnFwdLayer& L = b.l[li];
   const int blk = blockIdx.x - b.app_blk0[li];
+  const int p0 = blk * L.app_rows, p1 = min(L.P, p0 + L.app_rows);
+  if (L.nseg == 1 && L.seg[0].col_begin == 0) {   // (every engine launch) the code the conv-launch riders run as well
+    tbn_bn_apply_rows(L.y, L.y_ld, L.seg[0].ptr, L.seg[0].ld, L.scale, L.shift, L.C, p0, p1);
+    return;
+  }
   const int G = L.C >> 2, RP = 256 / G;
   const int cg = threadIdx.x % G, rs = threadIdx.x / G;
   if (rs >= RP) return;
   const int c = cg * 4;
-  const int p0 = blk * L.app_rows, p1 = min(L.P, p0 + L.app_rows);
   const float4 sc = *reinterpret_cast<const float4*>(L.scale + c);
   const float4 sh = *reinterpret_cast<const float4*>(L.shift + c);
   int sg = 0;
@@ -133,8 +139,29 @@ static inline int apply_rows(int P, int C) {
   return RP * it;
 }
 
-int tbn_launch_bn_fwd_multi(BnFwdBatch& b, hipStream_t st) {
+int tbn_launch_bn_fwd_multi(BnFwdBatch& b, hipStream_t st) { return tbn_launch_bn_fwd_multi_defer(b, 0u, nullptr, st); }
+
+int tbn_rider_place(RiderP* r, int gemm_blocks) {
+  // behind the GEMM's workgroups by default: the dispatcher hands out workgroups in grid order, the GEMM tiles are the
+  // long jobs and the rider's short HBM-bound workgroups fill the CUs the last round of tiles leaves idle (longest first).
+  // TBN_RIDER_FRONT=1 (A/B knob) puts them in front instead, padded to a multiple of 8 so that the XCD-aware tile maps hold.
+  static const int front = tbn_env_int("TBN_RIDER_FRONT", 0, 0, 1);
+  if (r == nullptr || r->nblk <= 0) return gemm_blocks;
+  if (front) {
+    r->span = (r->nblk + 7) / 8 * 8;
+    r->first = 0;
+    r->gemm0 = r->span;
+  } else {
+    r->span = r->nblk;
+    r->first = gemm_blocks;
+    r->gemm0 = 0;
+  }
+  return gemm_blocks + r->span;
+}
+
+int tbn_launch_bn_fwd_multi_defer(BnFwdBatch& b, unsigned defer_mask, RiderP* rider, hipStream_t st) {
   TBN_REQUIRE(b.n >= 1 && b.n <= TBN_BN_MAXL, "bn_fwd_multi: %d layers", b.n);
+  TBN_REQUIRE(defer_mask == 0u || rider != nullptr, "bn_fwd_multi: deferred members need a rider descriptor");
   b.fin_blk0[0] = b.app_blk0[0] = 0;
   for (int i = 0; i < b.n; ++i) {
     BnFwdLayer& L = b.l[i];
@@ -146,10 +173,42 @@ int tbn_launch_bn_fwd_multi(BnFwdBatch& b, hipStream_t st) {
     L.app_rows = apply_rows(L.P, L.C);
     b.app_blk0[i + 1] = b.app_blk0[i] + cdiv(L.P, L.app_rows);
   }
-  if (!diag_skip_fin(16)) hipLaunchKernelGGL(bn_finalize_multi_kernel, dim3(b.fin_blk0[b.n]), dim3(256), 0, st, b);
+  if (!diag_skip_fin(16)) TBN_KLAUNCH(bn_finalize_multi_kernel, dim3(b.fin_blk0[b.n]), dim3(256), 0, st, b);
   TBN_CHECK_LAUNCH("bn_finalize_multi");
-  hipLaunchKernelGGL(bn_apply_multi_kernel, dim3(b.app_blk0[b.n]), dim3(256), 0, st, b);
-  TBN_CHECK_LAUNCH("bn_apply_multi");
+  if (defer_mask == 0u) {
+    TBN_KLAUNCH(bn_apply_multi_kernel, dim3(b.app_blk0[b.n]), dim3(256), 0, st, b);
+    TBN_CHECK_LAUNCH("bn_apply_multi");
+    return TBN_OK;
+  }
+  // members whose apply pass rides in a later conv launch: described in `rider`; the others run here, compacted
+  static thread_local BnFwdBatch now;
+  now.n = 0;
+  now.momentum = b.momentum;
+  now.eps = b.eps;
+  now.app_blk0[0] = 0;
+  memset(rider, 0, sizeof(*rider));
+  rider->kind = 1;
+  for (int i = 0; i < b.n; ++i) {
+    const BnFwdLayer& L = b.l[i];
+    const int blocks = b.app_blk0[i + 1] - b.app_blk0[i];
+    if (defer_mask & (1u << i)) {
+      TBN_REQUIRE(rider->n < TBN_RIDER_MAXL && L.nseg == 1 && L.seg[0].col_begin == 0, "bn_fwd_multi: rider holds at most %d single-segment layers", TBN_RIDER_MAXL);
+      RiderLayer& R = rider->l[rider->n];
+      R.y = L.y; R.y_ld = L.y_ld; R.out = L.seg[0].ptr; R.out_ld = L.seg[0].ld;
+      R.scale = L.scale; R.shift = L.shift; R.P = L.P; R.C = L.C; R.rows = L.app_rows;
+      rider->blk0[rider->n + 1] = rider->blk0[rider->n] + blocks;
+      ++rider->n;
+    } else {
+      now.l[now.n] = L;
+      now.app_blk0[now.n + 1] = now.app_blk0[now.n] + blocks;
+      ++now.n;
+    }
+  }
+  rider->nblk = rider->blk0[rider->n];
+  if (now.n > 0) {
+    TBN_KLAUNCH(bn_apply_multi_kernel, dim3(now.app_blk0[now.n]), dim3(256), 0, st, now);
+    TBN_CHECK_LAUNCH("bn_apply_multi");
+  }
   return TBN_OK;
 }
 
@@ -234,11 +293,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_multi_kernel(BnBwdBatch b) {
   const int li = find_layer(b.app_blk0, b.n, blockIdx.x);
   const BnBwdLayer& L = b.l[li];
   const int blk = blockIdx.x - b.app_blk0[li];
+  const int p0 = blk * L.app_rows, p1 = min(L.P, p0 + L.app_rows);
+  if (L.nseg == 1 && L.dz[0].col_begin == 0) {   // (every engine launch) the code the conv-launch riders run as well
+    tbn_bn_bwd_apply_rows(L.dz[0].ptr, L.dz[0].ld, L.y, L.y_ld, L.dy, L.scale, L.shift, L.coef, L.C, p0, p1);
+    return;
+  }
   const int C = L.C, G = C >> 2, RP = 256 / G;
   const int cg = threadIdx.x % G, rs = threadIdx.x / G;
   if (rs >= RP) return;
   const int c = cg * 4;
-  const int p0 = blk * L.app_rows, p1 = min(L.P, p0 + L.app_rows);
   int sg = 0;
   if (L.nseg > 1 && c >= L.dz[1].col_begin) sg = 1;
   if (L.nseg > 2 && c >= L.dz[2].col_begin) sg = 2;
@@ -281,8 +344,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_multi_kernel(BnBwdBatch b) {
   }
 }
 
-int tbn_launch_bn_bwd_multi(BnBwdBatch& b, hipStream_t st) {
+int tbn_launch_bn_bwd_multi(BnBwdBatch& b, hipStream_t st) { return tbn_launch_bn_bwd_multi_defer(b, 0u, nullptr, st); }
+
+int tbn_launch_bn_bwd_multi_defer(BnBwdBatch& b, unsigned defer_mask, RiderP* rider, hipStream_t st) {
   TBN_REQUIRE(b.n >= 1 && b.n <= TBN_BN_MAXL, "bn_bwd_multi: %d layers", b.n);
+  TBN_REQUIRE(defer_mask == 0u || rider != nullptr, "bn_bwd_multi: deferred members need a rider descriptor");
   b.red_blk0[0] = b.fin_blk0[0] = b.app_blk0[0] = 0;
   for (int i = 0; i < b.n; ++i) {
     BnBwdLayer& L = b.l[i];
@@ -308,12 +374,41 @@ int tbn_launch_bn_bwd_multi(BnBwdBatch& b, hipStream_t st) {
     b.app_blk0[i + 1] = b.app_blk0[i] + cdiv(L.P, L.app_rows);
   }
   if (b.red_blk0[b.n] > 0) {
-    hipLaunchKernelGGL(bn_bwd_reduce_multi_kernel, dim3(b.red_blk0[b.n]), dim3(256), 0, st, b);
+    TBN_KLAUNCH(bn_bwd_reduce_multi_kernel, dim3(b.red_blk0[b.n]), dim3(256), 0, st, b);
     TBN_CHECK_LAUNCH("bn_bwd_reduce_multi");
   }
-  if (!diag_skip_fin(32)) hipLaunchKernelGGL(bn_bwd_finalize_multi_kernel, dim3(b.fin_blk0[b.n]), dim3(256), 0, st, b);
+  if (!diag_skip_fin(32)) TBN_KLAUNCH(bn_bwd_finalize_multi_kernel, dim3(b.fin_blk0[b.n]), dim3(256), 0, st, b);
   TBN_CHECK_LAUNCH("bn_bwd_finalize_multi");
-  hipLaunchKernelGGL(bn_bwd_apply_multi_kernel, dim3(b.app_blk0[b.n]), dim3(256), 0, st, b);
-  TBN_CHECK_LAUNCH("bn_bwd_apply_multi");
+  if (defer_mask == 0u) {
+    TBN_KLAUNCH(bn_bwd_apply_multi_kernel, dim3(b.app_blk0[b.n]), dim3(256), 0, st, b);
+    TBN_CHECK_LAUNCH("bn_bwd_apply_multi");
+    return TBN_OK;
+  }
+  static thread_local BnBwdBatch now;
+  now.n = 0;
+  now.app_blk0[0] = 0;
+  memset(rider, 0, sizeof(*rider));
+  rider->kind = 2;
+  for (int i = 0; i < b.n; ++i) {
+    const BnBwdLayer& L = b.l[i];
+    const int blocks = b.app_blk0[i + 1] - b.app_blk0[i];
+    if (defer_mask & (1u << i)) {
+      TBN_REQUIRE(rider->n < TBN_RIDER_MAXL && L.nseg == 1 && L.dz[0].col_begin == 0, "bn_bwd_multi: rider holds at most %d single-segment layers", TBN_RIDER_MAXL);
+      RiderLayer& R = rider->l[rider->n];
+      R.y = L.y; R.y_ld = L.y_ld; R.out = L.dy; R.out_ld = L.y_ld; R.dz = L.dz[0].ptr; R.dz_ld = L.dz[0].ld;
+      R.scale = L.scale; R.shift = L.shift; R.coef = L.coef; R.P = L.P; R.C = L.C; R.rows = L.app_rows;
+      rider->blk0[rider->n + 1] = rider->blk0[rider->n] + blocks;
+      ++rider->n;
+    } else {
+      now.l[now.n] = L;
+      now.app_blk0[now.n + 1] = now.app_blk0[now.n] + blocks;
+      ++now.n;
+    }
+  }
+  rider->nblk = rider->blk0[rider->n];
+  if (now.n > 0) {
+    TBN_KLAUNCH(bn_bwd_apply_multi_kernel, dim3(now.app_blk0[now.n]), dim3(256), 0, st, now);
+    TBN_CHECK_LAUNCH("bn_bwd_apply_multi");
+  }
   return TBN_OK;
 }

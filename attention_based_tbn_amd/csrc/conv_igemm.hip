@@ -26,8 +26,10 @@
 #include <cstdlib>
 #include <type_traits>
 
+#include <cstring>
 #include "tbn_common.h"
 #include "tbn_kernels.h"
+#include "tbn_rider_dev.h"
 
 #define LDT 36  // LDS row pitch in floats (32 + 4): 16-B aligned rows, conflict-free b128 reads
 // Timing ablations of the main loop (scripts/conv_ablate.py) exist only in a -DTBN_ABLATE=1 build: as run-time
@@ -536,9 +538,10 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& p, const int bid, f
 }
 
 template <int MT, int NT, bool ROWMODE, int EPI, int STAGES, bool RED = false>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
+__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p, RiderP rider) {
   __shared__ __attribute__((aligned(16))) float lds[STAGES * (128 * MT + 32 * NT) * LDT];
-  conv_igemm_body<MT, NT, ROWMODE, EPI, STAGES, RED>(p, blockIdx.x, lds);
+  TBN_RIDER_DISPATCH(rider, bid)
+  conv_igemm_body<MT, NT, ROWMODE, EPI, STAGES, RED>(p, bid, lds);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -724,9 +727,10 @@ __device__ __forceinline__ void conv_halo_body(const ConvP& p, const int bid, fl
 }
 
 template <int MT, int NT, int EPI, bool RED>
-__global__ __launch_bounds__(256) void conv_halo_kernel(ConvP p) {
+__global__ __launch_bounds__(256) void conv_halo_kernel(ConvP p, RiderP rider) {
   extern __shared__ __attribute__((aligned(16))) float dyn_lds[];
-  conv_halo_body<MT, NT, EPI, RED>(p, blockIdx.x, dyn_lds);
+  TBN_RIDER_DISPATCH(rider, bid)
+  conv_halo_body<MT, NT, EPI, RED>(p, bid, dyn_lds);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -928,9 +932,10 @@ __device__ __forceinline__ void conv_dma_body(const ConvP& p, const int bid, flo
 }
 
 template <int MT, int NT, int EPI, bool RED>
-__global__ __launch_bounds__(256) void conv_dma_kernel(ConvP p) {
+__global__ __launch_bounds__(256) void conv_dma_kernel(ConvP p, RiderP rider) {
   __shared__ __attribute__((aligned(1024))) float lds[2 * (128 * MT + 32 * NT) * 32];
-  conv_dma_body<MT, NT, EPI, RED>(p, blockIdx.x, lds);
+  TBN_RIDER_DISPATCH(rider, bid)
+  conv_dma_body<MT, NT, EPI, RED>(p, bid, lds);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1107,9 +1112,10 @@ __device__ __forceinline__ void conv_sk4_body(const ConvP& p, const int bid, flo
 }
 
 template <int MT, int NT, int EPI, bool RED>
-__global__ __launch_bounds__(256) void conv_sk4_kernel(ConvP p) {
+__global__ __launch_bounds__(256) void conv_sk4_kernel(ConvP p, RiderP rider) {
   __shared__ __attribute__((aligned(16))) float lds[4 * (32 * MT + 32 * NT) * LDT];
-  conv_sk4_body<MT, NT, EPI, RED>(p, blockIdx.x, lds);
+  TBN_RIDER_DISPATCH(rider, bid)
+  conv_sk4_body<MT, NT, EPI, RED>(p, bid, lds);
 }
 
 // The four output-parity phases of a stride-2 data gradient in ONE launch: each phase alone is a small GEMM
@@ -1120,11 +1126,12 @@ struct ConvPhases {
   int n;
 };
 template <int MT, int NT, int STAGES, bool RED = false>
-__global__ __launch_bounds__(256) void conv_igemm_phases_kernel(ConvPhases q) {
+__global__ __launch_bounds__(256) void conv_igemm_phases_kernel(ConvPhases q, RiderP rider) {
   __shared__ __attribute__((aligned(16))) float lds[STAGES * (128 * MT + 32 * NT) * LDT];
+  TBN_RIDER_DISPATCH(rider, bid)
   int ph = 0;
-  while (ph + 1 < q.n && (int)blockIdx.x >= q.blk0[ph + 1]) ++ph;
-  conv_igemm_body<MT, NT, false, 3, STAGES, RED>(q.ph[ph], blockIdx.x - q.blk0[ph], lds);
+  while (ph + 1 < q.n && bid >= q.blk0[ph + 1]) ++ph;
+  conv_igemm_body<MT, NT, false, 3, STAGES, RED>(q.ph[ph], bid - q.blk0[ph], lds);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1430,26 +1437,27 @@ __global__ void weight_flip_transpose_kernel(const float* __restrict__ w, float*
 }
 
 // ------------------------------------------------------------------------------------------ host
+// `rd` = the rider riding in this launch (rd.span == 0: none), `grid` = GEMM workgroups + rd.span (tbn_rider_place)
 template <int MT, int NT, bool RM, int EPI, bool RED = false>
-static void launch_conv_e(const ConvP& p, hipStream_t st) {
+static void launch_conv_e(const ConvP& p, const RiderP& rd, int grid, hipStream_t st) {
   if (p.stages == 2)
-    TBN_LAUNCH((conv_igemm_kernel<MT, NT, RM, EPI, 2, RED>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, st, p);
+    TBN_LAUNCH((conv_igemm_kernel<MT, NT, RM, EPI, 2, RED>), dim3(grid), dim3(256), 0, st, p, rd);
   else
-    TBN_LAUNCH((conv_igemm_kernel<MT, NT, RM, EPI, 1, RED>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, st, p);
+    TBN_LAUNCH((conv_igemm_kernel<MT, NT, RM, EPI, 1, RED>), dim3(grid), dim3(256), 0, st, p, rd);
 }
 template <int MT, int NT, bool RM>
-static void launch_conv(const ConvP& p, hipStream_t st) {
+static void launch_conv(const ConvP& p, const RiderP& rd, int grid, hipStream_t st) {
   const bool scatter = (p.out_sy != 1) || (p.out_sx != 1);
   if (p.mode == CONV_EPI_STATS)
-    launch_conv_e<MT, NT, RM, 1>(p, st);
+    launch_conv_e<MT, NT, RM, 1>(p, rd, grid, st);
   else if (p.mode == CONV_EPI_EVAL)
-    launch_conv_e<MT, NT, RM, 2>(p, st);
+    launch_conv_e<MT, NT, RM, 2>(p, rd, grid, st);
   else if (!RM && scatter)
-    launch_conv_e<MT, NT, false, 3>(p, st);
+    launch_conv_e<MT, NT, false, 3>(p, rd, grid, st);
   else if (!RM && p.nred > 0)
-    launch_conv_e<MT, NT, false, 0, true>(p, st);
+    launch_conv_e<MT, NT, false, 0, true>(p, rd, grid, st);
   else
-    launch_conv_e<MT, NT, RM, 0>(p, st);
+    launch_conv_e<MT, NT, RM, 0>(p, rd, grid, st);
 }
 
 // LDS bytes of the halo kernel; 0 if the shape is not a 3x3 / stride 1 / pad 1 layer it handles
@@ -1459,7 +1467,7 @@ size_t tbn_conv_halo_lds_bytes(const ConvP& p, int mt, int nt) {
 }
 
 template <int MT, int NT, int EPI, bool RED>
-static int launch_halo_e(const ConvP& p, size_t lds_bytes, hipStream_t st) {
+static int launch_halo_e(const ConvP& p, const RiderP& rd, int grid, size_t lds_bytes, hipStream_t st) {
   static size_t allowed = 64 * 1024;   // per instantiation: raise the dynamic-LDS limit once when a shape needs it
   if (lds_bytes > allowed) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_kernel<MT, NT, EPI, RED>),
@@ -1469,41 +1477,41 @@ static int launch_halo_e(const ConvP& p, size_t lds_bytes, hipStream_t st) {
     }
     allowed = 160 * 1024;
   }
-  TBN_LAUNCH((conv_halo_kernel<MT, NT, EPI, RED>), dim3(p.tiles_m * p.tiles_n), dim3(256), lds_bytes, st, p);
+  TBN_LAUNCH((conv_halo_kernel<MT, NT, EPI, RED>), dim3(grid), dim3(256), lds_bytes, st, p, rd);
   return TBN_OK;
 }
 template <int MT, int NT>
-static int launch_halo(const ConvP& p, size_t lds_bytes, hipStream_t st) {
-  if (p.mode == CONV_EPI_STATS) return launch_halo_e<MT, NT, 1, false>(p, lds_bytes, st);
-  if (p.mode == CONV_EPI_EVAL) return launch_halo_e<MT, NT, 2, false>(p, lds_bytes, st);
-  if (p.nred > 0) return launch_halo_e<MT, NT, 0, true>(p, lds_bytes, st);
-  return launch_halo_e<MT, NT, 0, false>(p, lds_bytes, st);
+static int launch_halo(const ConvP& p, const RiderP& rd, int grid, size_t lds_bytes, hipStream_t st) {
+  if (p.mode == CONV_EPI_STATS) return launch_halo_e<MT, NT, 1, false>(p, rd, grid, lds_bytes, st);
+  if (p.mode == CONV_EPI_EVAL) return launch_halo_e<MT, NT, 2, false>(p, rd, grid, lds_bytes, st);
+  if (p.nred > 0) return launch_halo_e<MT, NT, 0, true>(p, rd, grid, lds_bytes, st);
+  return launch_halo_e<MT, NT, 0, false>(p, rd, grid, lds_bytes, st);
 }
 
 template <int MT, int NT>
-static void launch_sk4(const ConvP& p, hipStream_t st) {
-  const dim3 grid(p.tiles_m * p.tiles_n);
+static void launch_sk4(const ConvP& p, const RiderP& rd, int nblocks, hipStream_t st) {
+  const dim3 grid(nblocks);
   if (p.mode == CONV_EPI_STATS)
-    TBN_LAUNCH((conv_sk4_kernel<MT, NT, 1, false>), grid, dim3(256), 0, st, p);
+    TBN_LAUNCH((conv_sk4_kernel<MT, NT, 1, false>), grid, dim3(256), 0, st, p, rd);
   else if (p.mode == CONV_EPI_EVAL)
-    TBN_LAUNCH((conv_sk4_kernel<MT, NT, 2, false>), grid, dim3(256), 0, st, p);
+    TBN_LAUNCH((conv_sk4_kernel<MT, NT, 2, false>), grid, dim3(256), 0, st, p, rd);
   else if (p.nred > 0)
-    TBN_LAUNCH((conv_sk4_kernel<MT, NT, 0, true>), grid, dim3(256), 0, st, p);
+    TBN_LAUNCH((conv_sk4_kernel<MT, NT, 0, true>), grid, dim3(256), 0, st, p, rd);
   else
-    TBN_LAUNCH((conv_sk4_kernel<MT, NT, 0, false>), grid, dim3(256), 0, st, p);
+    TBN_LAUNCH((conv_sk4_kernel<MT, NT, 0, false>), grid, dim3(256), 0, st, p, rd);
 }
 
 template <int MT, int NT>
-static void launch_dma(const ConvP& p, hipStream_t st) {
-  const dim3 grid(p.tiles_m * p.tiles_n);
+static void launch_dma(const ConvP& p, const RiderP& rd, int nblocks, hipStream_t st) {
+  const dim3 grid(nblocks);
   if (p.mode == CONV_EPI_STATS)
-    TBN_LAUNCH((conv_dma_kernel<MT, NT, 1, false>), grid, dim3(256), 0, st, p);
+    TBN_LAUNCH((conv_dma_kernel<MT, NT, 1, false>), grid, dim3(256), 0, st, p, rd);
   else if (p.mode == CONV_EPI_EVAL)
-    TBN_LAUNCH((conv_dma_kernel<MT, NT, 2, false>), grid, dim3(256), 0, st, p);
+    TBN_LAUNCH((conv_dma_kernel<MT, NT, 2, false>), grid, dim3(256), 0, st, p, rd);
   else if (p.nred > 0)
-    TBN_LAUNCH((conv_dma_kernel<MT, NT, 0, true>), grid, dim3(256), 0, st, p);
+    TBN_LAUNCH((conv_dma_kernel<MT, NT, 0, true>), grid, dim3(256), 0, st, p, rd);
   else
-    TBN_LAUNCH((conv_dma_kernel<MT, NT, 0, false>), grid, dim3(256), 0, st, p);
+    TBN_LAUNCH((conv_dma_kernel<MT, NT, 0, false>), grid, dim3(256), 0, st, p, rd);
 }
 
 void tbn_conv_pick_tile(int M, int Cout, int K, int* mt_out, int* nt_out) {
@@ -1552,7 +1560,12 @@ static double conv_alg_bytes(const ConvP& p, int rowmode) {
   return 4.0 * (in + (double)p.Cout * p.Krow + out);
 }
 
-static int launch_conv_tiles(ConvP& p, int rowmode, int mt, int nt, hipStream_t st) {
+static int launch_conv_tiles(ConvP& p, int rowmode, int mt, int nt, hipStream_t st, const RiderP* rider) {
+  static thread_local RiderP rd;      // by value into the kernel arguments (zeroed: no rider)
+  if (rider != nullptr)
+    rd = *rider;
+  else
+    memset(&rd, 0, sizeof(rd));
   if ((mt <= 0 || nt <= 0) && !rowmode && p.out_sy == 1 && p.out_sx == 1) {
     // heuristic launches (the head Linear layers: M = 96 ... 768 rows): a grid of 128-row tiles that leaves most CUs
     // idle takes the split-K tile kernel instead (never with partial-sum epilogues: their row count is the caller's)
@@ -1569,12 +1582,13 @@ static int launch_conv_tiles(ConvP& p, int rowmode, int mt, int nt, hipStream_t 
     const bool scatter = (p.out_sy != 1) || (p.out_sx != 1);
     TBN_REQUIRE(!scatter && mt <= 2 && nt <= 2, "conv: the split-K tile kernel does not handle this launch");
     p.tiles_m = cdiv(p.M, 32 * mt);
+    const int grid = tbn_rider_place(&rd, p.tiles_m * p.tiles_n);
     char nm[64];
     const int epi = p.mode == CONV_EPI_STATS ? 1 : (p.mode == CONV_EPI_EVAL ? 2 : 0);
     snprintf(nm, sizeof(nm), "conv_sk4_kernel<%d, %d, %d%s>", mt, nt, epi, (p.nred > 0 && epi == 0) ? ", true" : "");
     tbn_prof_begin(nm, p.alg_flops, st, conv_alg_bytes(p, rowmode));
 #define TBN_SCASE(MTv, NTv) \
-  if (mt == MTv && nt == NTv) launch_sk4<MTv, NTv>(p, st);
+  if (mt == MTv && nt == NTv) launch_sk4<MTv, NTv>(p, rd, grid, st);
     TBN_SCASE(1, 1) TBN_SCASE(1, 2) TBN_SCASE(2, 1) TBN_SCASE(2, 2)
 #undef TBN_SCASE
     tbn_prof_end(st);
@@ -1584,12 +1598,13 @@ static int launch_conv_tiles(ConvP& p, int rowmode, int mt, int nt, hipStream_t 
   if (p.halo == 2 && !rowmode) {   // LDS-DMA staging
     const bool scatter = (p.out_sy != 1) || (p.out_sx != 1);
     TBN_REQUIRE(!scatter && mt <= 2 && nt <= 4, "conv: the LDS-DMA kernel does not handle this launch");
+    const int grid = tbn_rider_place(&rd, p.tiles_m * p.tiles_n);
     char nm[64];
     const int epi = p.mode == CONV_EPI_STATS ? 1 : (p.mode == CONV_EPI_EVAL ? 2 : 0);
     snprintf(nm, sizeof(nm), "conv_dma_kernel<%d, %d, %d%s>", mt, nt, epi, (p.nred > 0 && epi == 0) ? ", true" : "");
     tbn_prof_begin(nm, p.alg_flops, st, conv_alg_bytes(p, rowmode));
 #define TBN_DCASE(MTv, NTv) \
-  if (mt == MTv && nt == NTv) launch_dma<MTv, NTv>(p, st);
+  if (mt == MTv && nt == NTv) launch_dma<MTv, NTv>(p, rd, grid, st);
     TBN_DCASE(1, 1) TBN_DCASE(1, 2) TBN_DCASE(1, 3) TBN_DCASE(1, 4) TBN_DCASE(2, 1) TBN_DCASE(2, 2) TBN_DCASE(2, 3) TBN_DCASE(2, 4)
 #undef TBN_DCASE
     tbn_prof_end(st);
@@ -1600,13 +1615,14 @@ static int launch_conv_tiles(ConvP& p, int rowmode, int mt, int nt, hipStream_t 
     const size_t lds_bytes = tbn_conv_halo_lds_bytes(p, mt, nt);
     TBN_REQUIRE(lds_bytes > 0 && lds_bytes <= 160 * 1024, "conv: the LDS-halo kernel does not handle this shape / tile");
     TBN_REQUIRE(mt <= 2 && nt <= 4, "conv: unsupported halo tile %dx%d", mt, nt);
+    const int grid = tbn_rider_place(&rd, p.tiles_m * p.tiles_n);
     char nm[64];
     const int epi = p.mode == CONV_EPI_STATS ? 1 : (p.mode == CONV_EPI_EVAL ? 2 : 0);
     snprintf(nm, sizeof(nm), "conv_halo_kernel<%d, %d, %d%s>", mt, nt, epi, (p.nred > 0 && epi == 0) ? ", true" : "");
     tbn_prof_begin(nm, p.alg_flops, st, conv_alg_bytes(p, rowmode));
     int rc = TBN_OK;
 #define TBN_HCASE(MTv, NTv) \
-  if (mt == MTv && nt == NTv) rc = launch_halo<MTv, NTv>(p, lds_bytes, st);
+  if (mt == MTv && nt == NTv) rc = launch_halo<MTv, NTv>(p, rd, grid, lds_bytes, st);
     TBN_HCASE(1, 1) TBN_HCASE(1, 2) TBN_HCASE(1, 3) TBN_HCASE(1, 4) TBN_HCASE(2, 1) TBN_HCASE(2, 2) TBN_HCASE(2, 3) TBN_HCASE(2, 4)
 #undef TBN_HCASE
     tbn_prof_end(st);
@@ -1614,6 +1630,7 @@ static int launch_conv_tiles(ConvP& p, int rowmode, int mt, int nt, hipStream_t 
     TBN_CHECK_LAUNCH("conv_halo");
     return TBN_OK;
   }
+  const int grid = tbn_rider_place(&rd, p.tiles_m * p.tiles_n);
   {
     char nm[64];
     const int epi = p.mode == CONV_EPI_STATS ? 1 : (p.mode == CONV_EPI_EVAL ? 2 : ((p.out_sy != 1 || p.out_sx != 1) ? 3 : 0));
@@ -1624,9 +1641,9 @@ static int launch_conv_tiles(ConvP& p, int rowmode, int mt, int nt, hipStream_t 
 #define TBN_CASE(MTv, NTv)                                     \
   if (mt == MTv && nt == NTv) {                                \
     if (rowmode)                                               \
-      launch_conv<MTv, NTv, true>(p, st);                      \
+      launch_conv<MTv, NTv, true>(p, rd, grid, st);            \
     else                                                       \
-      launch_conv<MTv, NTv, false>(p, st);                     \
+      launch_conv<MTv, NTv, false>(p, rd, grid, st);           \
   } else
   TBN_CASE(1, 1) TBN_CASE(1, 2) TBN_CASE(1, 3) TBN_CASE(1, 4) TBN_CASE(2, 1) TBN_CASE(2, 2) TBN_CASE(2, 3)
   TBN_CASE(2, 4) {
@@ -1726,11 +1743,11 @@ static int conv_prepare(ConvP& p, int rowmode, int* single) {
   return TBN_OK;
 }
 
-int tbn_launch_conv(ConvP p, int rowmode, int mt, int nt, hipStream_t st) {
+int tbn_launch_conv(ConvP p, int rowmode, int mt, int nt, hipStream_t st, const RiderP* rider) {
   int single = 0;
   const int prc = conv_prepare(p, rowmode, &single);
   if (prc != TBN_OK) return prc;
-  if (single) return launch_conv_tiles(p, rowmode, mt, nt, st);
+  if (single) return launch_conv_tiles(p, rowmode, mt, nt, st, rider);
   TBN_REQUIRE(!rowmode && p.stride == 1 && p.R == p.S && p.R * p.S <= 9, "conv: unsupported strided data gradient");
   const double flops_total = p.alg_flops;
   const int full_M = p.N * p.OH * p.OW;
@@ -1841,8 +1858,14 @@ int tbn_launch_conv(ConvP p, int rowmode, int mt, int nt, hipStream_t st) {
     snprintf(nm, sizeof(nm), "conv_igemm_phases_kernel<%d, %d, %d%s>", pmt, pnt, stages, p.nred > 0 ? ", true" : "");
     tbn_prof_begin(nm, flops_total, st, conv_alg_bytes(p, 0));
   }
+  static thread_local RiderP prd;
+  if (rider != nullptr)
+    prd = *rider;
+  else
+    memset(&prd, 0, sizeof(prd));
+  const int pgrid = tbn_rider_place(&prd, phases.blk0[phases.n]);
 #define TBN_PLAUNCH(MTv, NTv, STv, REDv) \
-  TBN_LAUNCH((conv_igemm_phases_kernel<MTv, NTv, STv, REDv>), dim3(phases.blk0[phases.n]), dim3(256), 0, st, phases)
+  TBN_LAUNCH((conv_igemm_phases_kernel<MTv, NTv, STv, REDv>), dim3(pgrid), dim3(256), 0, st, phases, prd)
 #define TBN_PCASE(MTv, NTv)                          \
   if (pmt == MTv && pnt == NTv) {                    \
     if (stages == 2) {                               \
@@ -1879,20 +1902,22 @@ struct ConvPair {
   int blk1;   // first workgroup of member 1
 };
 template <int MT, int NT, int EPI, int STAGES, bool RED>
-__global__ __launch_bounds__(256) void conv_pair_igemm_kernel(ConvPair q) {
+__global__ __launch_bounds__(256) void conv_pair_igemm_kernel(ConvPair q, RiderP rider) {
   __shared__ __attribute__((aligned(16))) float lds[STAGES * (128 * MT + 32 * NT) * LDT];
-  const int mi = (int)blockIdx.x >= q.blk1 ? 1 : 0;
-  conv_igemm_body<MT, NT, false, EPI, STAGES, RED>(q.m[mi], blockIdx.x - (mi ? q.blk1 : 0), lds);
+  TBN_RIDER_DISPATCH(rider, bid)
+  const int mi = bid >= q.blk1 ? 1 : 0;
+  conv_igemm_body<MT, NT, false, EPI, STAGES, RED>(q.m[mi], bid - (mi ? q.blk1 : 0), lds);
 }
 template <int MT, int NT, int EPI, bool RED>
-__global__ __launch_bounds__(256) void conv_pair_halo_kernel(ConvPair q) {
+__global__ __launch_bounds__(256) void conv_pair_halo_kernel(ConvPair q, RiderP rider) {
   extern __shared__ __attribute__((aligned(16))) float dyn_lds[];
-  const int mi = (int)blockIdx.x >= q.blk1 ? 1 : 0;
-  conv_halo_body<MT, NT, EPI, RED>(q.m[mi], blockIdx.x - (mi ? q.blk1 : 0), dyn_lds);
+  TBN_RIDER_DISPATCH(rider, bid)
+  const int mi = bid >= q.blk1 ? 1 : 0;
+  conv_halo_body<MT, NT, EPI, RED>(q.m[mi], bid - (mi ? q.blk1 : 0), dyn_lds);
 }
 
 template <int MT, int NT, int EPI, bool RED>
-static int launch_pair_v(const ConvPair& q, int blocks, int variant, size_t lds_bytes, hipStream_t st) {
+static int launch_pair_v(const ConvPair& q, const RiderP& rd, int blocks, int variant, size_t lds_bytes, hipStream_t st) {
   if (variant == 0) {   // LDS-halo members
     static size_t allowed = 64 * 1024;
     if (lds_bytes > allowed) {
@@ -1903,28 +1928,33 @@ static int launch_pair_v(const ConvPair& q, int blocks, int variant, size_t lds_
       }
       allowed = 160 * 1024;
     }
-    TBN_LAUNCH((conv_pair_halo_kernel<MT, NT, EPI, RED>), dim3(blocks), dim3(256), lds_bytes, st, q);
+    TBN_LAUNCH((conv_pair_halo_kernel<MT, NT, EPI, RED>), dim3(blocks), dim3(256), lds_bytes, st, q, rd);
   } else if (variant == 2) {
-    TBN_LAUNCH((conv_pair_igemm_kernel<MT, NT, EPI, 2, RED>), dim3(blocks), dim3(256), 0, st, q);
+    TBN_LAUNCH((conv_pair_igemm_kernel<MT, NT, EPI, 2, RED>), dim3(blocks), dim3(256), 0, st, q, rd);
   } else {
-    TBN_LAUNCH((conv_pair_igemm_kernel<MT, NT, EPI, 1, RED>), dim3(blocks), dim3(256), 0, st, q);
+    TBN_LAUNCH((conv_pair_igemm_kernel<MT, NT, EPI, 1, RED>), dim3(blocks), dim3(256), 0, st, q, rd);
   }
   return TBN_OK;
 }
 template <int MT, int NT>
-static int launch_pair(const ConvPair& q, int blocks, int variant, size_t lds_bytes, hipStream_t st) {
+static int launch_pair(const ConvPair& q, const RiderP& rd, int blocks, int variant, size_t lds_bytes, hipStream_t st) {
   const ConvP& p = q.m[0];
-  if (p.mode == CONV_EPI_STATS) return launch_pair_v<MT, NT, 1, false>(q, blocks, variant, lds_bytes, st);
-  if (p.mode == CONV_EPI_EVAL) return launch_pair_v<MT, NT, 2, false>(q, blocks, variant, lds_bytes, st);
-  if (p.nred > 0) return launch_pair_v<MT, NT, 0, true>(q, blocks, variant, lds_bytes, st);
-  return launch_pair_v<MT, NT, 0, false>(q, blocks, variant, lds_bytes, st);
+  if (p.mode == CONV_EPI_STATS) return launch_pair_v<MT, NT, 1, false>(q, rd, blocks, variant, lds_bytes, st);
+  if (p.mode == CONV_EPI_EVAL) return launch_pair_v<MT, NT, 2, false>(q, rd, blocks, variant, lds_bytes, st);
+  if (p.nred > 0) return launch_pair_v<MT, NT, 0, true>(q, rd, blocks, variant, lds_bytes, st);
+  return launch_pair_v<MT, NT, 0, false>(q, rd, blocks, variant, lds_bytes, st);
 }
 
 // variant: 0 LDS-halo (both members 3x3 / stride 1), 1 / 2 register-staged generic kernel with 1 / 2 LDS stages.
 // Tiles: (1,1) (1,2) (2,1) (2,2).  Both members: unit-stride launches (no parity phases), same epilogue mode, reduce
 // segments on both or on neither.
-int tbn_launch_conv_pair(ConvP a, ConvP b, int variant, int mt, int nt, hipStream_t st) {
+int tbn_launch_conv_pair(ConvP a, ConvP b, int variant, int mt, int nt, hipStream_t st, const RiderP* rider) {
   static thread_local ConvPair q;
+  static thread_local RiderP rd;
+  if (rider != nullptr)
+    rd = *rider;
+  else
+    memset(&rd, 0, sizeof(rd));
   int sa = 0, sb = 0;
   int rc = conv_prepare(a, 0, &sa);
   if (rc != TBN_OK) return rc;
@@ -1956,7 +1986,7 @@ int tbn_launch_conv_pair(ConvP a, ConvP b, int variant, int mt, int nt, hipStrea
     q.m[i] = *ms[i];
   }
   q.blk1 = ms[0]->tiles_m * ms[0]->tiles_n;
-  const int blocks = q.blk1 + ms[1]->tiles_m * ms[1]->tiles_n;
+  const int blocks = tbn_rider_place(&rd, q.blk1 + ms[1]->tiles_m * ms[1]->tiles_n);
   {
     char nm[64];
     const int epi = a.mode == CONV_EPI_STATS ? 1 : (a.mode == CONV_EPI_EVAL ? 2 : 0);
@@ -1965,10 +1995,10 @@ int tbn_launch_conv_pair(ConvP a, ConvP b, int variant, int mt, int nt, hipStrea
     tbn_prof_begin(nm, a.alg_flops + b.alg_flops, st, conv_alg_bytes(a, 0) + conv_alg_bytes(b, 0));
   }
   rc = TBN_OK;
-  if (mt == 1 && nt == 1) rc = launch_pair<1, 1>(q, blocks, variant, lds_bytes, st);
-  if (mt == 1 && nt == 2) rc = launch_pair<1, 2>(q, blocks, variant, lds_bytes, st);
-  if (mt == 2 && nt == 1) rc = launch_pair<2, 1>(q, blocks, variant, lds_bytes, st);
-  if (mt == 2 && nt == 2) rc = launch_pair<2, 2>(q, blocks, variant, lds_bytes, st);
+  if (mt == 1 && nt == 1) rc = launch_pair<1, 1>(q, rd, blocks, variant, lds_bytes, st);
+  if (mt == 1 && nt == 2) rc = launch_pair<1, 2>(q, rd, blocks, variant, lds_bytes, st);
+  if (mt == 2 && nt == 1) rc = launch_pair<2, 1>(q, rd, blocks, variant, lds_bytes, st);
+  if (mt == 2 && nt == 2) rc = launch_pair<2, 2>(q, rd, blocks, variant, lds_bytes, st);
   tbn_prof_end(st);
   if (rc != TBN_OK) return rc;
   TBN_CHECK_LAUNCH("conv_pair");
@@ -2144,16 +2174,16 @@ int tbn_launch_wgrad(WgradP p, int rowmode, float* dw, float* workspace, hipStre
     const size_t n = (size_t)p.Cout * p.K;
     const int n4 = (int)(n / 4);
     if (splits >= 32 && n4 < 64 * 1024)
-      hipLaunchKernelGGL(splitk_reduce_kernel<16>, dim3(cdiv(n4, 16)), dim3(256), 0, st, workspace, dw, n4, splits, n / 4);
+      TBN_KLAUNCH(splitk_reduce_kernel<16>, dim3(cdiv(n4, 16)), dim3(256), 0, st, workspace, dw, n4, splits, n / 4);
     else
-      hipLaunchKernelGGL(splitk_reduce_kernel<4>, dim3(cdiv(n4, 64)), dim3(256), 0, st, workspace, dw, n4, splits, n / 4);
+      TBN_KLAUNCH(splitk_reduce_kernel<4>, dim3(cdiv(n4, 64)), dim3(256), 0, st, workspace, dw, n4, splits, n / 4);
     TBN_CHECK_LAUNCH("splitk_reduce");
   }
   return TBN_OK;
 }
 
 int tbn_launch_weight_flip_transpose(const float* w, float* wt, int Cout, int taps, int Cin, hipStream_t st) {
-  hipLaunchKernelGGL(weight_flip_transpose_kernel, dim3(cdiv(Cin, 32), cdiv(Cout, 32), taps), dim3(256), 0, st, w,
+  TBN_KLAUNCH(weight_flip_transpose_kernel, dim3(cdiv(Cin, 32), cdiv(Cout, 32), taps), dim3(256), 0, st, w,
                      wt, Cout, taps, Cin);
   TBN_CHECK_LAUNCH("weight_flip_transpose");
   return TBN_OK;
@@ -2203,7 +2233,7 @@ int tbn_launch_weight_flip_transpose_all(const float* w, float* wt, const FlipTa
   if (tab.n == 0) return TBN_OK;
   for (int l = 0; l < tab.n; ++l)   // the kernel stages every tap of a tile at once: tile[9][32][33]
     TBN_REQUIRE(tab.taps[l] >= 1 && tab.taps[l] <= 9, "weight_flip: layer %d has %d taps (at most 9 = 3x3)", l, (int)tab.taps[l]);
-  hipLaunchKernelGGL(weight_flip_transpose_all_kernel, dim3(tab.blk0[tab.n]), dim3(256), 0, st, w, wt, tab);
+  TBN_KLAUNCH(weight_flip_transpose_all_kernel, dim3(tab.blk0[tab.n]), dim3(256), 0, st, w, wt, tab);
   TBN_CHECK_LAUNCH("weight_flip_transpose_all");
   return TBN_OK;
 }

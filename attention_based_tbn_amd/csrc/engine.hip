@@ -158,6 +158,17 @@ struct tbn_backbone_plan {
   // pool passes and 6-us finalize bubbles then sit under the other chain's GEMMs.  Sibling-pair launches (which put
   // 3x3 and double_3x3_1 into ONE grid) are not used in this mode.
   std::vector<Op> ops_b;
+  // Riders (tbn_backbone_params.flags & TBN_BACKBONE_RIDERS, one-chain program, training): per inception block the BN
+  // members whose elementwise pass runs inside the grid of a sibling GEMM launch (tbn_kernels.h RiderP)
+  struct BlockRiders {
+    int bn_g, bn_mid, bn_d2;        // the block's BN steps: fused 1x1 group | 3x3, double_3x3_1, pool_proj | double_3x3_2
+    int c3, cd2;                    // hosts: forward apply of the 1x1 range rides on c3's launch (or its pair launch); forward
+                                    // apply of 3x3 / pool_proj and all backward riders on double_3x3_2's forward / data gradient
+    unsigned g_defer, mid_defer;    // member bit masks of bn_g / bn_mid that ride
+  };
+  std::vector<BlockRiders> riders;
+  std::vector<int> bn_block;        // BN step -> block index (-1: stem)
+  int rider_launches[2] = {0, 0};   // conv launches of the last forward / backward pass that carried a rider (diagnostics)
   int out_buf;
   size_t weight_floats, chan_floats;
   // workspace layout (float offsets unless noted)
@@ -435,12 +446,29 @@ bool build_graph(tbn_backbone_plan* P) {
       P->convs[mc[nm]].slot_b = 3;
       mp[nm++] = 0;
     }
-    add_bn(P, nm, mc, mp);
+    const int bn_mid = add_bn(P, nm, mc, mp);
     {
       std::string n = pre + "_double_3x3_2";
       int co = B.cd2, db = O, dc = B.c1 + B.c3;
       cd2 = add_conv(P, 1, &n, &co, B.cd1, 3, B.stride, 1, T3, &db, &dc, false);
       bn_d2 = add_bn_conv(P, cd2);
+    }
+    {
+      // what can ride: a member whose destination is the block's OUTPUT buffer is read by nothing inside the block
+      tbn_backbone_plan::BlockRiders R;
+      R.bn_g = bn_g;
+      R.bn_mid = bn_mid;
+      R.bn_d2 = bn_d2;
+      R.c3 = c3;
+      R.cd2 = cd2;
+      R.g_defer = R.mid_defer = 0;
+      const BnStep& sg = P->bns[bn_g];
+      for (int k = 0; k < sg.n; ++k)
+        if (P->convs[sg.conv[k]].parts[sg.part[k]].dst_buf == O) R.g_defer |= 1u << k;
+      const BnStep& sm = P->bns[bn_mid];
+      for (int k = 0; k < sm.n; ++k)
+        if (P->convs[sm.conv[k]].parts[sm.part[k]].dst_buf == O) R.mid_defer |= 1u << k;
+      P->riders.push_back(R);
     }
     {
       // branch-mode program of this block (see tbn_backbone_plan::ops_b).  Scratch slots: launch-stream layers keep 0 / 1
@@ -483,6 +511,10 @@ bool build_graph(tbn_backbone_plan* P) {
     w = ow;
   }
   P->out_buf = x;
+  P->bn_block.assign(P->bns.size(), -1);
+  for (size_t b = 0; b < P->riders.size(); ++b) {
+    P->bn_block[P->riders[b].bn_g] = P->bn_block[P->riders[b].bn_mid] = P->bn_block[P->riders[b].bn_d2] = (int)b;
+  }
 
   // backward write order: walk ops in reverse, first writer of a d-buffer overwrites, later ones add.  The LAST
   // writer holds the final gradient in its epilogue.
@@ -974,6 +1006,12 @@ size_t tbn_backbone_workspace_bytes(const tbn_backbone_plan* P, int training) {
   return training ? P->total_bytes_train : P->total_bytes_eval;
 }
 int tbn_backbone_num_streams(const tbn_backbone_plan* P) { return P->ops_b.empty() ? 1 : 2; }
+int tbn_backbone_rider_launches(const tbn_backbone_plan* P, int* forward, int* backward) {
+  TBN_REQUIRE(P != nullptr, "rider_launches: null plan");
+  if (forward) *forward = P->rider_launches[0];
+  if (backward) *backward = P->rider_launches[1];
+  return TBN_OK;
+}
 int tbn_backbone_out_shape(const tbn_backbone_plan* P, int* h, int* w, int* c) {
   const Buf& b = P->bufs[P->out_buf];
   if (h) *h = b.H;
@@ -1242,6 +1280,12 @@ int tbn_backbone_forward(const tbn_backbone_plan* P, int training, const float* 
     }
   };
   const hipStream_t st_main = st;
+  // riders: one-chain training program only; off while the profiler brackets the conv launches (a rider's time would be
+  // charged to its host GEMM)
+  const bool use_riders = training && !br && (prm->flags & TBN_BACKBONE_RIDERS) != 0 && !tbn_prof_enabled() && !P->riders.empty();
+  RiderP pend_rider;        // a BN apply waiting for the conv launch that hosts it
+  int pend_host = -1;
+  if (training) PM->rider_launches[0] = 0;
   for (const Op& o : (br ? P->ops_b : P->ops)) {
     st = (br && o.side) ? side : st_main;   // the stream this op launches on
     if (o.kind == OP_FORK || o.kind == OP_JOIN) {
@@ -1256,13 +1300,18 @@ int tbn_backbone_forward(const tbn_backbone_plan* P, int training, const float* 
       const Conv& c = P->convs[o.idx];
       const Conv::FwdTune& T = c.ft[tr];
       if (!br && c.pair_prev >= 0 && P->convs[c.pair_prev].ft[tr].pair) continue;   // ran with its sibling
+      const RiderP* rd = (pend_host == o.idx) ? &pend_rider : nullptr;
+      if (rd != nullptr) {
+        pend_host = -1;
+        ++PM->rider_launches[0];
+      }
       if (!br && c.pair_next >= 0 && T.pair) {
         const Conv& c2 = P->convs[c.pair_next];
         ConvP pa, pb;
         fwd_params(c, pa);
         fwd_params(c2, pb);
         tbn_prof_label(("fwd " + c.parts[0].name + " | " + c2.parts[0].name).c_str());
-        TBN_TRY(tbn_launch_conv_pair(pa, pb, T.p_variant, T.p_mt, T.p_nt, st));
+        TBN_TRY(tbn_launch_conv_pair(pa, pb, T.p_variant, T.p_mt, T.p_nt, st, rd));
         continue;
       }
       ConvP p;
@@ -1292,7 +1341,7 @@ int tbn_backbone_forward(const tbn_backbone_plan* P, int training, const float* 
           if (q.pooled) p.raw_seg1 = i + 1;
         }
       }
-      TBN_TRY(tbn_launch_conv(p, c.stem, T.mt, T.nt, st));
+      TBN_TRY(tbn_launch_conv(p, c.stem, T.mt, T.nt, st, rd));
     } else if (o.kind == OP_PREPOOL) {
       // pool_proj: 3x3 average of its conv output columns -> BN input (+ its batch statistics in training)
       const Conv& c = P->convs[o.idx];
@@ -1388,7 +1437,18 @@ int tbn_backbone_forward(const tbn_backbone_plan* P, int training, const float* 
         L.seg[0].ld = db.C;
         L.seg[0].col_begin = 0;
       }
-      if (!diag_skip(2)) TBN_TRY(tbn_launch_bn_fwd_multi(fb, st));
+      unsigned defer = 0;
+      if (use_riders && P->bn_block[o.idx] >= 0) {
+        const tbn_backbone_plan::BlockRiders& R = P->riders[P->bn_block[o.idx]];
+        if (o.idx == R.bn_g && R.g_defer) {
+          defer = R.g_defer;
+          pend_host = R.c3;
+        } else if (o.idx == R.bn_mid && R.mid_defer) {
+          defer = R.mid_defer;
+          pend_host = R.cd2;
+        }
+      }
+      if (!diag_skip(2)) TBN_TRY(tbn_launch_bn_fwd_multi_defer(fb, defer, defer ? &pend_rider : nullptr, st));
     } else {
       const Pool& q = P->pools[o.idx];
       const Buf& ib = P->bufs[q.inbuf];
@@ -1404,6 +1464,7 @@ int tbn_backbone_forward(const tbn_backbone_plan* P, int training, const float* 
     }
   }
   st = st_main;   // (every block ends with a JOIN: the launch stream has seen all side-stream work)
+  TBN_REQUIRE(pend_host < 0, "backbone_forward: a rider was left without its host launch (conv %d)", pend_host);
   *features_out = ws + P->bufs[P->out_buf].off;
   return TBN_OK;
 }
@@ -1695,6 +1756,10 @@ int tbn_backbone_backward(const tbn_backbone_plan* P, const float* dfeatures, co
   TBN_TRY(tbn_launch_weight_flip_transpose_all(prm->weight, ws + P->wt_off, P->flip, st));
   const std::vector<Op>& prog = br ? P->ops_b : P->ops;
   const hipStream_t st_main = st;
+  const bool use_riders = !br && (prm->flags & TBN_BACKBONE_RIDERS) != 0 && !tbn_prof_enabled() && !P->riders.empty();
+  RiderP bpend;             // BN-backward applies waiting for the data-gradient launch that hosts them
+  int bpend_host = -1;
+  PM->rider_launches[1] = 0;
   // branch mode without an aux stream: the weight gradients share ONE split-K slab region, so those of the side chain
   // are issued on the launch stream once the side chain has been joined
   int deferred[8], ndef = 0;
@@ -1777,14 +1842,11 @@ int tbn_backbone_backward(const tbn_backbone_plan* P, const float* dfeatures, co
         }
         continue;
       }
-      BnBwdBatch bb;
-      memset(&bb, 0, sizeof(bb));
-      bb.n = s.n;
-      for (int k = 0; k < s.n; ++k) {
-        const Conv& c = P->convs[s.conv[k]];
-        const Part& q = c.parts[s.part[k]];
+      // one member of a batched BN-backward step: layer (conv ci, part pk) with the scratch slot `slot`
+      auto fill_layer = [&](BnBwdLayer& L, int ci, int pk, int slot) {
+        const Conv& c = P->convs[ci];
+        const Part& q = c.parts[pk];
         const Buf& db = P->bufs[q.dst_buf];
-        BnBwdLayer& L = bb.l[k];
         L.nseg = 1;
         L.dz[0].ptr = dptr(q.dst_buf) + q.dst_choff;
         L.dz[0].ld = db.C;
@@ -1807,17 +1869,46 @@ int tbn_backbone_backward(const tbn_backbone_plan* P, const float* dfeatures, co
           const bool paired = !br && ((f.pair_next >= 0 && f.pair_dgrad) || (f.pair_prev >= 0 && P->convs[f.pair_prev].pair_dgrad));
           L.ext_parts = tbn_conv_red_rows(R, f.inH, f.inW, f.stride, paired ? 128 * dmt : tile_rows(f.d_halo, dmt));
         } else {
-          L.partial = partial + (size_t)(s.slot0 + k) * P->partial_floats;
+          L.partial = partial + (size_t)slot * P->partial_floats;
           L.ext_parts = 0;
         }
-        L.coef = coef + (size_t)(s.slot0 + k) * 3 * 1024;
-        const bool first = (s.conv[k] == 0);
+        L.coef = coef + (size_t)slot * 3 * 1024;
+        const bool first = (ci == 0);
         const bool bg = g->dgamma && g->dbeta && (g->bn_grad_layers == 2 || (g->bn_grad_layers == 1 && first));
         L.dgamma = bg ? g->dgamma + q.c_off : nullptr;
         L.dbeta = bg ? g->dbeta + q.c_off : nullptr;
         L.dbias = g->dbias + q.c_off;
+      };
+      BnBwdBatch bb;
+      memset(&bb, 0, sizeof(bb));
+      unsigned skip = 0, defer = 0;      // members another step already handled / members whose apply pass rides
+      const tbn_backbone_plan::BlockRiders* RB = (use_riders && P->bn_block[o.idx] >= 0) ? &P->riders[P->bn_block[o.idx]] : nullptr;
+      if (RB != nullptr && o.idx == RB->bn_g) skip = RB->g_defer;
+      if (RB != nullptr && o.idx == RB->bn_mid) skip = RB->mid_defer;
+      for (int k = 0; k < s.n; ++k)
+        if (!(skip & (1u << k))) {
+          fill_layer(bb.l[bb.n], s.conv[k], s.part[k], s.slot0 + bb.n);
+          ++bb.n;
+        }
+      if (RB != nullptr && o.idx == RB->bn_d2 && (RB->g_defer | RB->mid_defer)) {
+        // first BN step of the block in this (reverse) walk: the block's output gradient is final, so the members of the
+        // LATER steps that write nothing the block's remaining GEMMs read -- `1x1`, `3x3`, `pool_proj` -- are reduced /
+        // finalized here with double_3x3_2, and their apply pass rides in double_3x3_2's data-gradient launch
+        for (int pass = 0; pass < 2; ++pass) {
+          const BnStep& t = P->bns[pass == 0 ? RB->bn_g : RB->bn_mid];
+          const unsigned m = pass == 0 ? RB->g_defer : RB->mid_defer;
+          for (int k = 0; k < t.n; ++k)
+            if (m & (1u << k)) {
+              TBN_REQUIRE(bb.n < TBN_BN_MAXL, "backbone_backward: too many rider members");
+              defer |= 1u << bb.n;
+              fill_layer(bb.l[bb.n], t.conv[k], t.part[k], bb.n);
+              ++bb.n;
+            }
+        }
+        bpend_host = RB->cd2;
       }
-      if (!diag_skip(8)) TBN_TRY(tbn_launch_bn_bwd_multi(bb, st));
+      if (bb.n == 0) continue;      // every member rode in an earlier launch
+      if (!diag_skip(8)) TBN_TRY(tbn_launch_bn_bwd_multi_defer(bb, defer, defer ? &bpend : nullptr, st));
       continue;
     }
     const Conv& c = P->convs[o.idx];
@@ -1849,9 +1940,15 @@ int tbn_backbone_backward(const tbn_backbone_plan* P, const float* dfeatures, co
       tbn_prof_label(("dgrad " + c.parts[c.nparts - 1].name).c_str());
       ConvP p;
       fill_dgrad(P, c, ws, R, &p);
-      TBN_TRY(tbn_launch_conv(p, 0, c.d_mt, c.d_nt, st));
+      const RiderP* rd = (bpend_host == o.idx) ? &bpend : nullptr;
+      if (rd != nullptr) {
+        bpend_host = -1;
+        ++PM->rider_launches[1];
+      }
+      TBN_TRY(tbn_launch_conv(p, 0, c.d_mt, c.d_nt, st, rd));
     }
   }
+  TBN_REQUIRE(bpend_host < 0, "backbone_backward: a rider was left without its host launch (conv %d)", bpend_host);
   return TBN_OK;   // `join` joins the aux stream: everything the caller enqueues on `st` next sees the weight gradients
 }
 

@@ -163,7 +163,7 @@ extern "C" int tbn_frames_to_tensor(const unsigned char* frames, int n_img, int 
   const size_t planes = (size_t)(n_img / stack) * channels * stack;
   const size_t g = planes * (size_t)((out_h + kFrameRows - 1) / kFrameRows);
   TBN_REQUIRE(g < (1ull << 31), "frames_to_tensor: too many output planes");
-  hipLaunchKernelGGL(frames_to_tensor_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, p, mean, std_dev);
+  TBN_KLAUNCH(frames_to_tensor_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, p, mean, std_dev);
   TBN_CHECK_LAUNCH("frames_to_tensor");
   return TBN_OK;
 }

@@ -356,7 +356,7 @@ extern "C" {
 int tbn_pe_concat_fwd(const float* feat, int feat_ld, const float* pe, float* out, int out_ld, int r, int t, int c,
                       int pe_dim, void* stream) {
   TBN_REQUIRE(out_ld >= c + pe_dim, "pe_concat: out_ld too small");
-  hipLaunchKernelGGL(pe_concat_kernel, dim3(ew_grid((size_t)r * t * out_ld)), dim3(256), 0, (hipStream_t)stream, feat,
+  TBN_KLAUNCH(pe_concat_kernel, dim3(ew_grid((size_t)r * t * out_ld)), dim3(256), 0, (hipStream_t)stream, feat,
                      feat_ld, pe, out, out_ld, r, t, c, pe_dim);
   TBN_CHECK_LAUNCH("pe_concat");
   return TBN_OK;
@@ -371,7 +371,7 @@ static int gn_ok(int c, int groups) {
 int tbn_groupnorm_fwd(const float* x, float* y, const float* gamma, const float* beta, float* save_mean,
                       float* save_rstd, int r, int t, int c, int groups, float eps, void* stream) {
   TBN_REQUIRE(gn_ok(c, groups), "groupnorm: channels/group must be 4*2^k (<=256)");
-  hipLaunchKernelGGL(groupnorm_fwd_kernel, dim3(r), dim3(256), 0, (hipStream_t)stream, x, y, gamma, beta, save_mean,
+  TBN_KLAUNCH(groupnorm_fwd_kernel, dim3(r), dim3(256), 0, (hipStream_t)stream, x, y, gamma, beta, save_mean,
                      save_rstd, t, c, groups, eps);
   TBN_CHECK_LAUNCH("groupnorm_fwd");
   return TBN_OK;
@@ -381,14 +381,14 @@ int tbn_groupnorm_bwd(const float* dy, const float* x, const float* gamma, const
                       const float* save_rstd, float* dx, float* dgamma_part, float* dbeta_part, int r, int t, int c,
                       int groups, void* stream) {
   TBN_REQUIRE(gn_ok(c, groups), "groupnorm: channels/group must be 4*2^k (<=256)");
-  hipLaunchKernelGGL(groupnorm_bwd_kernel, dim3(r), dim3(256), 0, (hipStream_t)stream, dy, x, gamma, save_mean,
+  TBN_KLAUNCH(groupnorm_bwd_kernel, dim3(r), dim3(256), 0, (hipStream_t)stream, dy, x, gamma, save_mean,
                      save_rstd, dx, dgamma_part, dbeta_part, t, c, groups);
   TBN_CHECK_LAUNCH("groupnorm_bwd");
   return TBN_OK;
 }
 
 int tbn_colsum(const float* x, int x_ld, float* out, int rows, int cols, void* stream) {
-  hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(cols, 32)), dim3(256), 0, (hipStream_t)stream, x, x_ld, out, rows, cols);
+  TBN_KLAUNCH(colsum_kernel, dim3(cdiv(cols, 32)), dim3(256), 0, (hipStream_t)stream, x, x_ld, out, rows, cols);
   TBN_CHECK_LAUNCH("colsum");
   return TBN_OK;
 }
@@ -403,13 +403,13 @@ int tbn_mha_q1_fwd(const float* q, const float* kv, const float* drop_mask, floa
   float* pdrop = probs + (size_t)r * heads * t;
   const int blocks = cdiv(r * heads, 4);
   if (t <= 16)
-    hipLaunchKernelGGL((mha_q1_fwd_kernel<16>), dim3(blocks), dim3(256), 0, st, q, kv, drop_mask, ctx, probs, pdrop, r,
+    TBN_KLAUNCH((mha_q1_fwd_kernel<16>), dim3(blocks), dim3(256), 0, st, q, kv, drop_mask, ctx, probs, pdrop, r,
                        t, e, heads, scale);
   else
-    hipLaunchKernelGGL((mha_q1_fwd_kernel<32>), dim3(blocks), dim3(256), 0, st, q, kv, drop_mask, ctx, probs, pdrop, r,
+    TBN_KLAUNCH((mha_q1_fwd_kernel<32>), dim3(blocks), dim3(256), 0, st, q, kv, drop_mask, ctx, probs, pdrop, r,
                        t, e, heads, scale);
   TBN_CHECK_LAUNCH("mha_q1_fwd");
-  hipLaunchKernelGGL(head_mean_kernel, dim3(cdiv(r * t, 256)), dim3(256), 0, st, pdrop, avg_w, r, t, heads);
+  TBN_KLAUNCH(head_mean_kernel, dim3(cdiv(r * t, 256)), dim3(256), 0, st, pdrop, avg_w, r, t, heads);
   TBN_CHECK_LAUNCH("head_mean");
   return TBN_OK;
 }
@@ -422,47 +422,47 @@ int tbn_mha_q1_bwd(const float* dctx, const float* davg_w, const float* q, const
   hipStream_t st = (hipStream_t)stream;
   const int blocks = cdiv(r * heads, 4);
   if (t <= 16)
-    hipLaunchKernelGGL((mha_q1_bwd_kernel<16>), dim3(blocks), dim3(256), 0, st, dctx, davg_w, q, kv, probs, drop_mask,
+    TBN_KLAUNCH((mha_q1_bwd_kernel<16>), dim3(blocks), dim3(256), 0, st, dctx, davg_w, q, kv, probs, drop_mask,
                        dq, dkv, r, t, e, heads, scale);
   else
-    hipLaunchKernelGGL((mha_q1_bwd_kernel<32>), dim3(blocks), dim3(256), 0, st, dctx, davg_w, q, kv, probs, drop_mask,
+    TBN_KLAUNCH((mha_q1_bwd_kernel<32>), dim3(blocks), dim3(256), 0, st, dctx, davg_w, q, kv, probs, drop_mask,
                        dq, dkv, r, t, e, heads, scale);
   TBN_CHECK_LAUNCH("mha_q1_bwd");
   return TBN_OK;
 }
 
 int tbn_weighted_sum_fwd(const float* feat, const float* w, float* out, int out_ld, int r, int t, int c, void* stream) {
-  hipLaunchKernelGGL(weighted_sum_fwd_kernel, dim3(ew_grid((size_t)r * c)), dim3(256), 0, (hipStream_t)stream, feat, w,
+  TBN_KLAUNCH(weighted_sum_fwd_kernel, dim3(ew_grid((size_t)r * c)), dim3(256), 0, (hipStream_t)stream, feat, w,
                      out, out_ld, r, t, c);
   TBN_CHECK_LAUNCH("weighted_sum_fwd");
   return TBN_OK;
 }
 int tbn_weighted_sum_bwd(const float* dout, int dout_ld, const float* w, float* dfeat, int r, int t, int c,
                          void* stream) {
-  hipLaunchKernelGGL(weighted_sum_bwd_kernel, dim3(ew_grid((size_t)r * t * c)), dim3(256), 0, (hipStream_t)stream,
+  TBN_KLAUNCH(weighted_sum_bwd_kernel, dim3(ew_grid((size_t)r * t * c)), dim3(256), 0, (hipStream_t)stream,
                      dout, dout_ld, w, dfeat, r, t, c);
   TBN_CHECK_LAUNCH("weighted_sum_bwd");
   return TBN_OK;
 }
 int tbn_segment_mean_fwd(const float* x, float* out, int b, int n, int c, void* stream) {
-  hipLaunchKernelGGL(segment_mean_fwd_kernel, dim3(ew_grid((size_t)b * c)), dim3(256), 0, (hipStream_t)stream, x, out,
+  TBN_KLAUNCH(segment_mean_fwd_kernel, dim3(ew_grid((size_t)b * c)), dim3(256), 0, (hipStream_t)stream, x, out,
                      b, n, c);
   TBN_CHECK_LAUNCH("segment_mean_fwd");
   return TBN_OK;
 }
 int tbn_segment_mean_bwd(const float* dout, float* dx, int b, int n, int c, void* stream) {
-  hipLaunchKernelGGL(segment_mean_bwd_kernel, dim3(ew_grid((size_t)b * n * c)), dim3(256), 0, (hipStream_t)stream,
+  TBN_KLAUNCH(segment_mean_bwd_kernel, dim3(ew_grid((size_t)b * n * c)), dim3(256), 0, (hipStream_t)stream,
                      dout, dx, b, n, c);
   TBN_CHECK_LAUNCH("segment_mean_bwd");
   return TBN_OK;
 }
 int tbn_mul_mask(const float* x, const float* mask, float* y, size_t count, void* stream) {
-  hipLaunchKernelGGL(mul_mask_kernel, dim3(ew_grid(count)), dim3(256), 0, (hipStream_t)stream, x, mask, y, count);
+  TBN_KLAUNCH(mul_mask_kernel, dim3(ew_grid(count)), dim3(256), 0, (hipStream_t)stream, x, mask, y, count);
   TBN_CHECK_LAUNCH("mul_mask");
   return TBN_OK;
 }
 int tbn_relu_mask_bwd(const float* dy, const float* y, const float* mask, float* dx, size_t count, void* stream) {
-  hipLaunchKernelGGL(relu_mask_bwd_kernel, dim3(ew_grid(count)), dim3(256), 0, (hipStream_t)stream, dy, y, mask, dx,
+  TBN_KLAUNCH(relu_mask_bwd_kernel, dim3(ew_grid(count)), dim3(256), 0, (hipStream_t)stream, dy, y, mask, dx,
                      count);
   TBN_CHECK_LAUNCH("relu_mask_bwd");
   return TBN_OK;

@@ -63,7 +63,7 @@ int tbn_launch_maxpool_fwd(const float* in, int in_ld, float* out, int out_ld, u
                            int C, int OH, int OW, int stride, int pad, hipStream_t st) {
   TBN_REQUIRE(C % 4 == 0 && in_ld % 4 == 0 && out_ld % 4 == 0, "maxpool: C / pitches must be multiples of 4");
   TBN_REQUIRE((size_t)N * H * W * (C / 4) < (1ull << 31), "maxpool: too many elements per call");
-  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(ew_grid((size_t)N * OH * OW * C / 4)), dim3(256), 0, st, in, in_ld, out,
+  TBN_KLAUNCH(maxpool_fwd_kernel, dim3(ew_grid((size_t)N * OH * OW * C / 4)), dim3(256), 0, st, in, in_ld, out,
                      out_ld, argmax, N, H, W, C, OH, OW, stride, pad, make_pixdecode(C / 4, OW, OH));
   TBN_CHECK_LAUNCH("maxpool_fwd");
   return TBN_OK;
@@ -177,13 +177,13 @@ int tbn_launch_maxpool_bwd(const float* dout, int dout_ld, const uint8_t* argmax
   TBN_REQUIRE((size_t)N * H * W * (C / 4) < (1ull << 31), "maxpool_bwd: too many elements per call");
   if (stride == 2 && pad == 0) {
     const int NQ = N * ((H + 1) / 2) * ((W + 1) / 2);
-    hipLaunchKernelGGL(maxpool_bwd2x2_kernel, dim3(ew_grid((size_t)NQ * C / 4)), dim3(256), 0, st,
+    TBN_KLAUNCH(maxpool_bwd2x2_kernel, dim3(ew_grid((size_t)NQ * C / 4)), dim3(256), 0, st,
                        make_poolblk(dout, dout_ld, argmax, H, W, OH, OW, C), din, din_ld, NQ, C, accumulate,
                        make_fastdiv((uint32_t)(C / 4)));
     TBN_CHECK_LAUNCH("maxpool_bwd2x2");
     return TBN_OK;
   }
-  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(ew_grid((size_t)N * H * W * C / 4)), dim3(256), 0, st, dout, dout_ld,
+  TBN_KLAUNCH(maxpool_bwd_kernel, dim3(ew_grid((size_t)N * H * W * C / 4)), dim3(256), 0, st, dout, dout_ld,
                      argmax, din, din_ld, N, H, W, C, OH, OW, stride, pad, accumulate, make_pixdecode(C / 4, W, H));
   TBN_CHECK_LAUNCH("maxpool_bwd");
   return TBN_OK;
@@ -225,7 +225,7 @@ int tbn_launch_avgpool3_fwd(const float* in, int in_ld, float* out, int out_ld, 
                             int accumulate, hipStream_t st) {
   TBN_REQUIRE(C % 4 == 0 && in_ld % 4 == 0 && out_ld % 4 == 0, "avgpool: C / pitches must be multiples of 4");
   TBN_REQUIRE((size_t)N * H * W * (C / 4) < (1ull << 31), "avgpool: too many elements per call");
-  hipLaunchKernelGGL(avgpool3_kernel, dim3(ew_grid((size_t)N * H * W * C / 4)), dim3(256), 0, st, in, in_ld, out,
+  TBN_KLAUNCH(avgpool3_kernel, dim3(ew_grid((size_t)N * H * W * C / 4)), dim3(256), 0, st, in, in_ld, out,
                      out_ld, N, H, W, C, accumulate, make_pixdecode(C / 4, W, H));
   TBN_CHECK_LAUNCH("avgpool3");
   return TBN_OK;
@@ -274,7 +274,7 @@ int tbn_launch_spatial_mean_fwd(const float* in, int in_ld, float* out, int out_
   TBN_REQUIRE(C % 4 == 0 && C <= 1024 && in_ld % 4 == 0 && out_ld % 4 == 0,
               "spatial_mean: C / pitches must be multiples of 4, C <= 1024");
   const int G = C / 4, GL = G < 64 ? G : 64;
-  hipLaunchKernelGGL(spatial_mean_fwd_kernel, dim3(N * (freq_only ? W : 1), cdiv(G, GL)), dim3(256), 0, st, in, in_ld, out,
+  TBN_KLAUNCH(spatial_mean_fwd_kernel, dim3(N * (freq_only ? W : 1), cdiv(G, GL)), dim3(256), 0, st, in, in_ld, out,
                      out_ld, N, H, W, C, freq_only);
   TBN_CHECK_LAUNCH("spatial_mean_fwd");
   return TBN_OK;
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(256) void spatial_mean_bwd_kernel(const float* __re
 int tbn_launch_spatial_mean_bwd(const float* dout, int dout_ld, float* din, int din_ld, int N, int H, int W, int C,
                                 int freq_only, hipStream_t st) {
   TBN_REQUIRE(C % 4 == 0 && din_ld % 4 == 0 && dout_ld % 4 == 0, "spatial_mean_bwd: bad C / pitches");
-  hipLaunchKernelGGL(spatial_mean_bwd_kernel, dim3(ew_grid((size_t)N * H * W * C / 4)), dim3(256), 0, st, dout,
+  TBN_KLAUNCH(spatial_mean_bwd_kernel, dim3(ew_grid((size_t)N * H * W * C / 4)), dim3(256), 0, st, dout,
                      dout_ld, din, din_ld, N, H, W, C, freq_only);
   TBN_CHECK_LAUNCH("spatial_mean_bwd");
   return TBN_OK;
@@ -357,10 +357,10 @@ int tbn_launch_nchw_to_s2d_pad(const float* in, float* out, int N, int C, int H,
   const int HP = (H + 1) / 2 + 3, WP = (W + 1) / 2 + 3;
   const dim3 grid(ew_grid((size_t)N * HP * WP));
   switch (C) {
-    case 1: hipLaunchKernelGGL(nchw_to_s2d_pad_kernel<1>, grid, dim3(256), 0, st, in, out, N, C, H, W, HP, WP); break;
-    case 3: hipLaunchKernelGGL(nchw_to_s2d_pad_kernel<3>, grid, dim3(256), 0, st, in, out, N, C, H, W, HP, WP); break;
-    case 10: hipLaunchKernelGGL(nchw_to_s2d_pad_kernel<10>, grid, dim3(256), 0, st, in, out, N, C, H, W, HP, WP); break;
-    default: hipLaunchKernelGGL(nchw_to_s2d_pad_kernel<0>, grid, dim3(256), 0, st, in, out, N, C, H, W, HP, WP); break;
+    case 1: TBN_KLAUNCH(nchw_to_s2d_pad_kernel<1>, grid, dim3(256), 0, st, in, out, N, C, H, W, HP, WP); break;
+    case 3: TBN_KLAUNCH(nchw_to_s2d_pad_kernel<3>, grid, dim3(256), 0, st, in, out, N, C, H, W, HP, WP); break;
+    case 10: TBN_KLAUNCH(nchw_to_s2d_pad_kernel<10>, grid, dim3(256), 0, st, in, out, N, C, H, W, HP, WP); break;
+    default: TBN_KLAUNCH(nchw_to_s2d_pad_kernel<0>, grid, dim3(256), 0, st, in, out, N, C, H, W, HP, WP); break;
   }
   TBN_CHECK_LAUNCH("nchw_to_s2d_pad");
   return TBN_OK;
@@ -424,9 +424,9 @@ int tbn_launch_nchw_to_nhwc_pad(const float* in, float* out, int N, int C, int H
   TBN_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0 && HP >= H + 3 && WP >= W + 3, "nchw_to_nhwc_pad: bad extents");
   const dim3 grid(ew_grid((size_t)N * HP * WP));
   if (C == 10)
-    hipLaunchKernelGGL(nchw_to_nhwc_pad_kernel<10>, grid, dim3(256), 0, st, in, out, N, C, H, W, HP, WP);
+    TBN_KLAUNCH(nchw_to_nhwc_pad_kernel<10>, grid, dim3(256), 0, st, in, out, N, C, H, W, HP, WP);
   else
-    hipLaunchKernelGGL(nchw_to_nhwc_pad_kernel<0>, grid, dim3(256), 0, st, in, out, N, C, H, W, HP, WP);
+    TBN_KLAUNCH(nchw_to_nhwc_pad_kernel<0>, grid, dim3(256), 0, st, in, out, N, C, H, W, HP, WP);
   TBN_CHECK_LAUNCH("nchw_to_nhwc_pad");
   return TBN_OK;
 }
@@ -449,23 +449,23 @@ __global__ void unpack_stem_wgrad_rows_kernel(const float* __restrict__ dwp, flo
   }
 }
 int tbn_launch_pack_stem_weight_rows(const float* w, float* wp, int Cout, int C, int RL, int K, hipStream_t st) {
-  hipLaunchKernelGGL(pack_stem_weight_rows_kernel, dim3(cdiv(Cout * K, 256)), dim3(256), 0, st, w, wp, Cout, C, RL, K);
+  TBN_KLAUNCH(pack_stem_weight_rows_kernel, dim3(cdiv(Cout * K, 256)), dim3(256), 0, st, w, wp, Cout, C, RL, K);
   TBN_CHECK_LAUNCH("pack_stem_weight_rows");
   return TBN_OK;
 }
 int tbn_launch_unpack_stem_wgrad_rows(const float* dwp, float* dw, int Cout, int C, int RL, hipStream_t st) {
-  hipLaunchKernelGGL(unpack_stem_wgrad_rows_kernel, dim3(cdiv(Cout * 49 * C, 256)), dim3(256), 0, st, dwp, dw, Cout, C, RL);
+  TBN_KLAUNCH(unpack_stem_wgrad_rows_kernel, dim3(cdiv(Cout * 49 * C, 256)), dim3(256), 0, st, dwp, dw, Cout, C, RL);
   TBN_CHECK_LAUNCH("unpack_stem_wgrad_rows");
   return TBN_OK;
 }
 
 int tbn_launch_pack_stem_weight_s2d(const float* w, float* wp, int Cout, int C, hipStream_t st) {
-  hipLaunchKernelGGL(pack_stem_weight_s2d_kernel, dim3(cdiv(Cout * 64 * C, 256)), dim3(256), 0, st, w, wp, Cout, C);
+  TBN_KLAUNCH(pack_stem_weight_s2d_kernel, dim3(cdiv(Cout * 64 * C, 256)), dim3(256), 0, st, w, wp, Cout, C);
   TBN_CHECK_LAUNCH("pack_stem_weight_s2d");
   return TBN_OK;
 }
 int tbn_launch_unpack_stem_wgrad_s2d(const float* dwp, float* dw, int Cout, int C, hipStream_t st) {
-  hipLaunchKernelGGL(unpack_stem_wgrad_s2d_kernel, dim3(cdiv(Cout * 49 * C, 256)), dim3(256), 0, st, dwp, dw, Cout, C);
+  TBN_KLAUNCH(unpack_stem_wgrad_s2d_kernel, dim3(cdiv(Cout * 49 * C, 256)), dim3(256), 0, st, dwp, dw, Cout, C);
   TBN_CHECK_LAUNCH("unpack_stem_wgrad_s2d");
   return TBN_OK;
 }

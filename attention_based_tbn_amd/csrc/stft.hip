@@ -219,7 +219,7 @@ int tbn_stft_logpower(const float* wave, int nseg, int len, const float* twiddle
   // 32-bit byte offsets inside a segment's samples and inside its 256 x W spectrogram
   TBN_REQUIRE(nseg <= 65535 && (size_t)len * 4 < (1ull << 31) && (size_t)STFT_BINS * W * 4 < (1ull << 31),
               "stft_logpower: too many segments / too long a waveform per call");
-  hipLaunchKernelGGL(stft_logpower_kernel, dim3(cdiv(W, STFT_FR), nseg, 2), dim3(256), 0, (hipStream_t)stream, wave, len, W,
+  TBN_KLAUNCH(stft_logpower_kernel, dim3(cdiv(W, STFT_FR), nseg, 2), dim3(256), 0, (hipStream_t)stream, wave, len, W,
                      twiddle, spec, eps);
   TBN_CHECK_LAUNCH("stft_logpower");
   return TBN_OK;

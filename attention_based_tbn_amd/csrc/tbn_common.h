@@ -1,6 +1,7 @@
 // Internal helpers shared by the HIP translation units of libtbn_hip.so (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stddef.h>
 
@@ -33,6 +34,23 @@ void tbn_set_error(const char* fmt, ...);
 // number is refused (the default is used) and every knob that is set is announced on stderr, so a stray variable can
 // neither make every launch fail nor silently change the kernels a run measures (round-4 advisor).
 int tbn_env_int(const char* name, int def, int lo, int hi);
+
+// Opt-in kernel TIMELINE (tbn_timeline_enable / tbn_timeline_dump in include/tbn_hip.h): every launch of the library gets a
+// pair of events that ride on its dispatch packet (begin / end of the kernel itself), so that one un-traced multi-stream
+// step can be laid out on a common clock -- rocprofv3's kernel trace makes the step host-bound (~40 us per intercepted
+// launch) and the modality streams stop overlapping, which is exactly what the timeline is meant to show.
+bool tbn_tl_on();
+void tbn_tl_events(const char* name, hipStream_t st, hipEvent_t* start, hipEvent_t* stop);
+#define TBN_KLAUNCH(kernel, grid, block, lds, st, ...)                                              \
+  do {                                                                                              \
+    if (tbn_tl_on()) {                                                                              \
+      hipEvent_t tl_a__, tl_b__;                                                                    \
+      tbn_tl_events(#kernel, st, &tl_a__, &tl_b__);                                                 \
+      hipExtLaunchKernelGGL(kernel, grid, block, lds, st, tl_a__, tl_b__, 0, __VA_ARGS__);          \
+    } else {                                                                                        \
+      hipLaunchKernelGGL(kernel, grid, block, lds, st, __VA_ARGS__);                                \
+    }                                                                                               \
+  } while (0)
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));

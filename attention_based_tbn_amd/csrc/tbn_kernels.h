@@ -78,6 +78,36 @@ struct ConvP {
   const float* fold_shift;
 };
 
+// ---- riders: elementwise BN passes of INDEPENDENT layers executed by extra workgroups of a conv-GEMM launch.
+// Inside an inception block (reference dataflow core/models/bn_inception_audio.py:437-1003, concat :485-493) the BN apply
+// of the `1x1` column range does not feed the `3x3 | double_3x3_1` GEMMs, the BN apply of `3x3` / `pool_proj` does not
+// feed `double_3x3_2`, and in backward the BN-backward apply of `1x1` / `3x3` / `pool_proj` does not feed the data gradient
+// of `double_3x3_2`.  Cross-stream dependencies are the expensive primitive on this runtime (DESIGN.md finding 15), so the
+// concurrency comes from ONE launch: the grid of the GEMM is extended by `span` workgroups that run the HBM-bound pass
+// (same device code as the stand-alone bn_*_multi kernels: bit-identical results) beside the MFMA-bound tiles.
+#define TBN_RIDER_MAXL 3
+struct RiderLayer {
+  const float* y;       // BN input rows (pitch y_ld)
+  const float* dz;      // kind 2: gradient wrt z (pitch dz_ld)
+  float* out;           // kind 1: z (pitch out_ld); kind 2: dy (pitch y_ld, in place over y)
+  const float* scale;
+  const float* shift;
+  const float* coef;    // kind 2: [3][C]
+  int y_ld, dz_ld, out_ld, P, C, rows;   // rows = pixel rows per rider workgroup
+};
+struct RiderP {
+  int span;     // grid slots reserved for the rider (0: none)
+  int first;    // first grid slot of the rider: 0 (front of the grid) or the GEMM's workgroup count (behind it)
+  int gemm0;    // grid slot of GEMM workgroup 0 (front placement: span, a multiple of 8 -- keeps the XCD-aware tile maps)
+  int nblk;     // rider workgroups that do work (<= span)
+  int kind;     // 1: z = relu(y * scale + shift);  2: dy = a * [z > 0] dz + b * y + c
+  int n;
+  int blk0[TBN_RIDER_MAXL + 1];
+  RiderLayer l[TBN_RIDER_MAXL];
+};
+// places a rider with `nblk` workgroups around a GEMM grid of `gemm_blocks`; returns the launch's grid size
+int tbn_rider_place(RiderP* r, int gemm_blocks);
+
 struct WgradP {
   const float* dy;
   const float* x;
@@ -120,14 +150,14 @@ bool tbn_prof_launch_events(hipEvent_t* start, hipEvent_t* stop);   // true: an 
     if (tbn_prof_launch_events(&tbn_e0__, &tbn_e1__))                                            \
       hipExtLaunchKernelGGL(kernel, grid, block, lds, st, tbn_e0__, tbn_e1__, 0, __VA_ARGS__);  \
     else                                                                                         \
-      hipLaunchKernelGGL(kernel, grid, block, lds, st, __VA_ARGS__);                             \
+      TBN_KLAUNCH(kernel, grid, block, lds, st, __VA_ARGS__);                                    \
   } while (0)
 
 // conv_igemm.hip
 void tbn_conv_pick_tile(int M, int Cout, int K, int* mt, int* nt);
-int tbn_launch_conv(ConvP p, int rowmode, int mt, int nt, hipStream_t st);
+int tbn_launch_conv(ConvP p, int rowmode, int mt, int nt, hipStream_t st, const RiderP* rider = nullptr);
 // two independent unit-stride convs in one launch (variant 0 LDS-halo, 1 / 2 generic with 1 / 2 LDS stages; tiles <= (2,2))
-int tbn_launch_conv_pair(ConvP a, ConvP b, int variant, int mt, int nt, hipStream_t st);
+int tbn_launch_conv_pair(ConvP a, ConvP b, int variant, int mt, int nt, hipStream_t st, const RiderP* rider = nullptr);
 int tbn_conv_red_rows(int N, int OH, int OW, int up, int tile_rows);   // tile_rows = M rows per workgroup tile (128 * mt; 32 * mt for the split-K tile kernel)
 size_t tbn_conv_halo_lds_bytes(const ConvP& p, int mt, int nt);   // 0: shape not handled by the LDS-halo kernel
 void tbn_wgrad_plan(int M, int Cout, int Cin, int taps, int* mt, int* nt, int* splits, int* rows_per_split);
@@ -204,6 +234,11 @@ struct BnBwdBatch {
 };
 int tbn_launch_bn_fwd_multi(BnFwdBatch& b, hipStream_t st);   // finalize + apply of every layer: 2 launches
 int tbn_launch_bn_bwd_multi(BnBwdBatch& b, hipStream_t st);   // reduce + finalize + apply: 3 launches
+// the same with some members' APPLY pass taken out (bit i of `defer_mask`): those are described in `*rider` instead (to be
+// executed inside a later conv launch: tbn_launch_conv(..., rider)); every member is still reduced / finalized here
+int tbn_launch_bn_fwd_multi_defer(BnFwdBatch& b, unsigned defer_mask, RiderP* rider, hipStream_t st);
+int tbn_launch_bn_bwd_multi_defer(BnBwdBatch& b, unsigned defer_mask, RiderP* rider, hipStream_t st);
+bool tbn_prof_enabled();   // the opt-in profiler brackets every conv launch: riders would be charged to their hosts
 int tbn_launch_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var, const float* bias,
                        float eps, float* scale, float* shift, int C, hipStream_t st);
 int tbn_bn_bwd_parts(int P, int C);

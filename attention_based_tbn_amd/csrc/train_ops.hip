@@ -180,7 +180,7 @@ int tbn_opt_sqnorm_partials(const tbn_opt_tensor* tensors, int num_tensors, floa
   int rc = fill_tab(&tab, tensors, num_tensors, false, false);
   if (rc != TBN_OK) return rc;
   if (tab.blk0[tab.n] == 0) return TBN_OK;
-  hipLaunchKernelGGL(opt_sqnorm_kernel, dim3(tab.blk0[tab.n]), dim3(256), 0, (hipStream_t)stream, tab, partials);
+  TBN_KLAUNCH(opt_sqnorm_kernel, dim3(tab.blk0[tab.n]), dim3(256), 0, (hipStream_t)stream, tab, partials);
   TBN_CHECK_LAUNCH("opt_sqnorm");
   return TBN_OK;
 }
@@ -189,7 +189,7 @@ int tbn_opt_clip_coef(const float* partials, int num_partials, float max_norm, f
                       void* stream) {
   TBN_REQUIRE(partials != nullptr && total_norm != nullptr && coef != nullptr && num_partials >= 0,
               "opt_clip_coef: bad argument");
-  hipLaunchKernelGGL(opt_clip_coef_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partials, num_partials, max_norm,
+  TBN_KLAUNCH(opt_clip_coef_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partials, num_partials, max_norm,
                      total_norm, coef);
   TBN_CHECK_LAUNCH("opt_clip_coef");
   return TBN_OK;
@@ -201,7 +201,7 @@ int tbn_opt_scale_grads(const tbn_opt_tensor* tensors, int num_tensors, const fl
   int rc = fill_tab(&tab, tensors, num_tensors, false, false);
   if (rc != TBN_OK) return rc;
   if (tab.blk0[tab.n] == 0) return TBN_OK;
-  hipLaunchKernelGGL(opt_scale_kernel, dim3(tab.blk0[tab.n]), dim3(256), 0, (hipStream_t)stream, tab, coef);
+  TBN_KLAUNCH(opt_scale_kernel, dim3(tab.blk0[tab.n]), dim3(256), 0, (hipStream_t)stream, tab, coef);
   TBN_CHECK_LAUNCH("opt_scale_grads");
   return TBN_OK;
 }
@@ -213,7 +213,7 @@ int tbn_opt_sgd_step(const tbn_opt_tensor* tensors, int num_tensors, float lr, f
   int rc = fill_tab(&tab, tensors, num_tensors, true, momentum != 0.f);
   if (rc != TBN_OK) return rc;
   if (tab.blk0[tab.n] == 0) return TBN_OK;
-  hipLaunchKernelGGL(opt_sgd_kernel, dim3(tab.blk0[tab.n]), dim3(256), 0, (hipStream_t)stream, tab, lr, momentum,
+  TBN_KLAUNCH(opt_sgd_kernel, dim3(tab.blk0[tab.n]), dim3(256), 0, (hipStream_t)stream, tab, lr, momentum,
                      weight_decay, grad_scale);
   TBN_CHECK_LAUNCH("opt_sgd_step");
   return TBN_OK;
@@ -274,7 +274,7 @@ extern "C" int tbn_topk_correct(const float* scores, int scores_ld, const long l
   TBN_REQUIRE(batch >= 0 && classes >= 1 && k >= 1 && k <= classes && scores_ld >= classes,
               "topk_correct: bad shape (B=%d, C=%d, k=%d)", batch, classes, k);
   if (batch == 0) return TBN_OK;
-  hipLaunchKernelGGL(topk_correct_kernel, dim3(cdiv(batch, 4)), dim3(256), 0, (hipStream_t)stream, scores, scores_ld,
+  TBN_KLAUNCH(topk_correct_kernel, dim3(cdiv(batch, 4)), dim3(256), 0, (hipStream_t)stream, scores, scores_ld,
                      target, batch, classes, k, correct, pred, conf_mat);
   TBN_CHECK_LAUNCH("topk_correct");
   return TBN_OK;

@@ -392,6 +392,8 @@ def main():
     ap.add_argument("--branch-streams", default=None,
                     help="diagnostic: comma-separated modalities (or 'all' / 'none') whose inception branches run on a side "
                          "stream (default: the model's policy -- only a lone backbone)")
+    ap.add_argument("--riders", default=None, choices=["on", "off"],
+                    help="diagnostic: BN apply / BN-backward apply passes riding in sibling GEMM launches (default: the model's)")
     ap.add_argument("--eval-chunk", type=int, default=0,
                     help="config 5: frames per engine call of the eval forward (default: the backbone's, 256)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -408,6 +410,10 @@ def main():
     ap.add_argument("--profile-every", type=int, default=0,
                     help="diagnostic (rocprofv3 / PMC passes): ALSO instrument every k-th step INSIDE the timed loop, so a "
                          "short traced run contains instrumented steps; the line then says timed_region_instrumented")
+    ap.add_argument("--timeline", default=None, metavar="CSV",
+                    help="diagnostic: after the timed loop run 4 more product steps with the library's kernel timeline on "
+                         "(tbn_timeline_enable: begin / end of every launch on a common clock, no external tracer) and write "
+                         "it to CSV for scripts/step_timeline.py -- the real overlap of the multi-stream step")
     ap.add_argument("--trace-streams", action="store_true",
                     help="diagnostic: after the timed loop run 3 more steps with HIP events around every backbone "
                          "forward / backward call and print (stderr) when each ran on the GPU and how long the host took "
@@ -540,6 +546,9 @@ def main():
         for b_, m in zip(bases, modality):
             b_.use_branch_streams = m in want
     branch = [b_.use_branch_streams for b_ in bases]
+    if args.riders is not None:
+        for b_ in bases:
+            b_.use_riders = args.riders == "on"
     if args.eval_chunk > 0:
         for b_ in bases:
             b_.eval_chunk = args.eval_chunk
@@ -646,6 +655,14 @@ def main():
         rank_ms = [1e3 * float(x.item()) / args.steps for x in every]      # each rank's own clock around the same K steps
         dt = max(float(x.item()) for x in every)                            # the job's time = the slowest rank
     assert os.environ.get("TBN_DIAG_SKIP") or torch.isfinite(loss).item(), "loss is not finite"
+    if args.timeline and rank == 0:
+        torch.cuda.synchronize()
+        L.tbn_timeline_enable(1)
+        for _ in range(4):
+            step()
+        torch.cuda.synchronize()
+        L.tbn_timeline_enable(0)
+        assert L.tbn_timeline_dump(args.timeline.encode()) == 0
     if args.trace_streams and rank == 0:
         from attention_based_tbn_amd import _lib
         for _ in range(3):
@@ -681,7 +698,8 @@ def main():
                        "parallelism": f"dp{world}" if world > 1 else "single",
                        "streams": {"modality_streams": bool(multi and len(modality) > 1),
                                    "weight_gradient_stream": [m for m, a_ in zip(modality, aux) if a_],
-                                   "branch_streams": [m for m, b_ in zip(modality, branch) if b_]},
+                                   "branch_streams": [m for m, b_ in zip(modality, branch) if b_],
+                                   "riders": [m for m, b_ in zip(modality, bases) if b_.use_riders]},
                        **({"inputs": "pinned host memory, PCIe copy every step (diagnostic)"} if args.host_inputs else {}),
                        **({"audio_input": "waveform (30695 samples), STFT kernel inside the timed step"} if args.stft_inputs else {})},
             "roofline": roofline,

@@ -83,7 +83,16 @@ typedef struct {
                                  so with pairing off the two programs agree bit for bit (tests/test_branch_gpu.py).  Joined before the
                                  call returns.  NULL = one chain.  Ignored (serial program) while the launch stream is
                                  being captured: forks inside a capture are what aux_stream's note below is about. */
+  int flags;                  /* TBN_BACKBONE_RIDERS (1): training passes of the one-chain program put the BN apply / BN-backward
+                                 apply of a block's INDEPENDENT column ranges into the grid of a sibling GEMM launch instead of
+                                 their own launches -- forward: `1x1` beside `3x3 | double_3x3_1`, `3x3` and `pool_proj` beside
+                                 `double_3x3_2`; backward: `1x1`, `3x3`, `pool_proj` beside the data gradient of `double_3x3_2`
+                                 (reference dataflow core/models/bn_inception_audio.py:437-1003: these branches only meet at the
+                                 concat, :485-493).  Same device code as the stand-alone passes: results are bit-identical with the
+                                 flag off (tests/test_riders_gpu.py).  Ignored in branch mode and while the opt-in profiler brackets
+                                 the conv launches. */
 } tbn_backbone_params;
+#define TBN_BACKBONE_RIDERS 1
 
 typedef struct {
   float* dweight;             /* same layout as weight; fully overwritten */
@@ -116,6 +125,16 @@ size_t tbn_backbone_workspace_bytes(const tbn_backbone_plan* plan, int training)
 int tbn_backbone_out_shape(const tbn_backbone_plan* plan, int* h, int* w, int* c);
 /* 2 when the plan holds a branch-mode program (tbn_backbone_params.side_stream is honoured), else 1 */
 int tbn_backbone_num_streams(const tbn_backbone_plan* plan);
+/* Opt-in kernel timeline (diagnostics; scripts/step_timeline.py reads the file): while enabled every launch of the library
+ * carries a pair of events on its dispatch packet; tbn_timeline_dump synchronises the device and writes one CSV row per
+ * launch (Kernel_Name, Queue_Id = stream, Start_Timestamp, End_Timestamp in ns on a common clock).  Unlike an external
+ * tracer it leaves the host's launch rate alone, so the overlap of the modality streams is the un-traced step's.
+ * enable(1) clears earlier records.  The reference has no counterpart (its only timing: core/tools/train.py:339-351). */
+int tbn_timeline_enable(int on);
+int tbn_timeline_dump(const char* path);
+/* diagnostics: how many conv launches of the plan's LAST training forward / backward pass carried a rider
+ * (tbn_backbone_params.flags & TBN_BACKBONE_RIDERS): 2 / 1 per average-pool inception block, 1 / 1 per stride-2 block */
+int tbn_backbone_rider_launches(const tbn_backbone_plan* plan, int* forward, int* backward);
 /* test / debug aid: location of one conv's tensors inside the workspace (floats). kind 0: z =
  * relu(bn(conv)) destination slice, 1: BN input y (overwritten by dy in backward), 2: gradient
  * wrt z (offset -1 when it is the caller-supplied dfeatures), 3: the conv's whole input buffer, 4: its training-mode

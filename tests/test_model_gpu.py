@@ -190,8 +190,10 @@ def test_product_bninception_factory_matches_reference():
 # product's gradients agree with fp64 to 1e-4 on every layer, test_backbone_all_layer_grads_forced_decisions).  A layer
 # whose kernel is WRONG (a dropped split-K slab, a transposed tile, a mis-ordered tap) shows relative L2 of order 1 and a
 # cosine far below 0.99, so the bound separates the two by an order of magnitude.
-PER_LAYER_L2 = 8e-2
-PER_LAYER_COS = 0.996
+# Observed (round 5, R = 96 and R = 192): the noise spreads evenly -- every layer sits at 1.1e-2 ... 1.6e-2 / cosine 0.99988 ...
+# 0.99994, the same figures as the per-backbone aggregates.
+PER_LAYER_L2 = 3e-2
+PER_LAYER_COS = 0.999
 
 
 def l2_err(a, b):

@@ -1,0 +1,73 @@
+"""GPU: riders (tbn_backbone_params.flags & TBN_BACKBONE_RIDERS) -- the BN apply / BN-backward apply of a block's
+independent column ranges executed by extra workgroups of a sibling GEMM launch (forward: `1x1` beside `3x3 |
+double_3x3_1`, `3x3` and `pool_proj` beside `double_3x3_2`; backward: all three beside the data gradient of
+`double_3x3_2`; reference dataflow core/models/bn_inception_audio.py:437-1003, the branches only meet at the concat
+:485-493).  The rider workgroups run the device code of the stand-alone bn_*_multi kernels, so a training step must give
+the same BITS with the flag on and off -- outputs, every gradient, the running statistics -- with the sibling-pair
+launches the autotuner picks left in place, with and without the weight-gradient stream, repeatedly (a race between a
+rider and its host, or a rider reading coefficients a later finalize already overwrote, need not show on the first
+try).  Both placements of the rider workgroups (behind / in front of the GEMM tiles) are covered."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+_WORKER = r'''
+import ctypes as C, sys, torch
+sys.path.insert(0, sys.argv[1])
+from attention_based_tbn_amd._lib import lib
+from attention_based_tbn_amd.core.models.bn_inception import BNInception
+DEV = torch.device("cuda")
+for cin, N, H, W in ((3, 6, 224, 224), (1, 5, 128, 256), (10, 3, 96, 96), (3, 24, 112, 112)):
+    torch.manual_seed(cin + N)
+    net = BNInception(1000, cin).to(DEV)
+    with torch.no_grad():
+        net.running_var.uniform_(0.5, 1.5); net.running_mean.normal_(0, 0.1)
+    net.set_bn_trainable(True, True)
+    net.use_branch_streams = False
+    x = torch.randn(N, cin, H, W, device=DEV)
+    rm0, rv0 = net.running_mean.clone(), net.running_var.clone()
+
+    def train_step(riders, aux):
+        net.train(); net.use_riders = riders; net.use_aux_stream = aux
+        net.running_mean.copy_(rm0); net.running_var.copy_(rv0)
+        net.zero_grad(set_to_none=True)
+        out = net(x)
+        (out.square().mean() + out.sum() * 1e-3).backward()
+        torch.cuda.synchronize()
+        return [out.detach().clone(), net.flat_weight.grad.clone(), net.flat_bias.grad.clone(), net.bn_weight_first.grad.clone(),
+                net.bn_weight_rest.grad.clone(), net.bn_bias_first.grad.clone(), net.bn_bias_rest.grad.clone(),
+                net.running_mean.clone(), net.running_var.clone()]
+
+    def counts():
+        f, b = C.c_int(), C.c_int()
+        assert lib().tbn_backbone_rider_launches(net._plans[(N, H, W)].handle, C.byref(f), C.byref(b)) == 0
+        return f.value, b.value
+
+    ref = train_step(False, False)                     # stand-alone BN passes (autotunes on first use)
+    assert counts() == (0, 0)
+    assert float(ref[1].abs().max()) > 0 and all(torch.isfinite(t).all() for t in ref)
+    for rep in range(3):
+        for aux in (False, True):
+            got = train_step(True, aux)
+            # 8 blocks with a 1x1 range and a pool_proj (two forward hosts each) + 3c / 4e (one: `3x3` beside double_3x3_2)
+            assert counts() == (18, 10), counts()
+            for i, (a, b) in enumerate(zip(got, ref)):
+                assert torch.equal(a, b), (cin, rep, aux, i, float((a - b).abs().max()))
+        assert all(torch.equal(a, b) for a, b in zip(train_step(False, True), ref))
+print("RIDERS_OK")
+'''
+
+
+@pytest.mark.parametrize("front", ["0", "1"])
+def test_riders_are_bit_identical_to_the_stand_alone_passes(tmp_path, front):
+    script = tmp_path / "riders_worker.py"
+    script.write_text(_WORKER)
+    env = dict(os.environ, TBN_RIDER_FRONT=front)
+    r = subprocess.run([sys.executable, str(script), ROOT], env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "RIDERS_OK" in r.stdout, (r.stdout[-1500:] + "\n----\n" + r.stderr[-3000:])
