@@ -122,6 +122,9 @@ SIGNATURES = {
     "tbn_weighted_sum_bwd": (c_i, [c_fp, c_i, c_fp, c_fp, c_i, c_i, c_i, c_fp]),
     "tbn_segment_mean_fwd": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_fp]),
     "tbn_segment_mean_bwd": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_fp]),
+    "tbn_dropout_fwd": (c_i, [c_fp, c_fp, c_f, c_fp, c_fp, c_sz, c_fp]),
+    "tbn_ce_heads_fwd": (c_i, [c_fp, c_i, c_i, c_i, C.POINTER(c_i), C.POINTER(c_i), C.POINTER(C.c_void_p), c_fp, c_fp, c_fp, c_fp]),
+    "tbn_ce_heads_bwd": (c_i, [c_fp, c_i, c_i, c_i, C.POINTER(c_i), C.POINTER(c_i), c_fp, c_fp, c_fp]),
     "tbn_mul_mask": (c_i, [c_fp, c_fp, c_fp, c_sz, c_fp]),
     "tbn_relu_mask_bwd": (c_i, [c_fp, c_fp, c_fp, c_fp, c_sz, c_fp]),
     "tbn_stft_twiddle_floats": (c_sz, []),

@@ -351,7 +351,121 @@ __global__ __launch_bounds__(256) void relu_mask_bwd_kernel(const float* dy, con
   }
 }
 
+// dropout from a caller-drawn uniform tensor: mask = rnd >= p ? 1 / (1 - p) : 0 (torch's nn.Dropout rule, the draw itself
+// stays torch's RNG), y = x * mask; the compare / cast / scale / multiply chain of four elementwise launches in one
+__global__ __launch_bounds__(256) void dropout_fwd_kernel(const float* __restrict__ x, const float* __restrict__ rnd,
+                                                          float p, float keep_scale, float* __restrict__ y,
+                                                          float* __restrict__ mask, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const float m = rnd[i] >= p ? keep_scale : 0.f;
+    mask[i] = m;
+    y[i] = x[i] * m;
+  }
+}
+
+// Cross entropy of several classification heads that share one score matrix (reference model.py:272-279: one
+// nn.CrossEntropyLoss per class key, summed): head h owns the columns [col0[h], col0[h] + ncls[h]) of scores (B, ld) and
+// int64 labels label[h][b].  One workgroup per (head, sample): max / sum-exp by wavefront reduction, then
+//   rowloss[h * B + b] = logsumexp - score[label],   dscores[b][c] = (softmax_c - [c == label]) / B   (columns outside every
+// head are left untouched: the caller zero-fills).  The mean over b is a fixed-order sum in ce_heads_mean_kernel
+// (deterministic); out-of-range labels poison the loss with NaN instead of reading out of bounds.
+struct CeHeads {
+  int n;
+  int col0[4], ncls[4];
+  const long long* label[4];
+};
+__global__ __launch_bounds__(256) void ce_heads_fwd_kernel(const float* __restrict__ scores, int ld, CeHeads hd, int B,
+                                                           float* __restrict__ rowloss, float* __restrict__ dscores) {
+  __shared__ float red[8];
+  const int h = blockIdx.x / B, b = blockIdx.x - h * B;
+  const int C = hd.ncls[h];
+  const float* s = scores + (size_t)b * ld + hd.col0[h];
+  float* d = dscores + (size_t)b * ld + hd.col0[h];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float mx = -INFINITY;
+  for (int c = tid; c < C; c += 256) mx = fmaxf(mx, s[c]);
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  if (lane == 0) red[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float se = 0.f;
+  for (int c = tid; c < C; c += 256) se += expf(s[c] - mx);
+  for (int o = 32; o > 0; o >>= 1) se += __shfl_xor(se, o);
+  if (lane == 0) red[4 + wave] = se;
+  __syncthreads();
+  se = (red[4] + red[5]) + (red[6] + red[7]);
+  const long long lab = hd.label[h][b];
+  const bool ok = lab >= 0 && lab < C;
+  const float lse = mx + logf(se), inv = 1.f / se, invB = 1.f / (float)B;
+  for (int c = tid; c < C; c += 256) d[c] = (expf(s[c] - mx) * inv - ((long long)c == lab ? 1.f : 0.f)) * invB;
+  if (tid == 0) rowloss[h * B + b] = ok ? lse - s[lab] : NAN;
+}
+__global__ __launch_bounds__(64) void ce_heads_mean_kernel(const float* __restrict__ rowloss, int B, int nheads,
+                                                           float* __restrict__ loss) {
+  const int h = blockIdx.x;
+  if (h >= nheads) return;
+  double acc = 0.0;
+  for (int b = threadIdx.x; b < B; b += 64) acc += (double)rowloss[h * B + b];
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  if (threadIdx.x == 0) loss[h] = (float)(acc / (double)B);
+}
+// dscores *= per-head upstream gradient (d total / d loss_h): the backward of the fused cross entropy
+__global__ __launch_bounds__(256) void ce_heads_bwd_kernel(const float* __restrict__ dsc, int ld, CeHeads hd, int B,
+                                                           const float* __restrict__ upstream, float* __restrict__ out) {
+  const int h = blockIdx.x / B, b = blockIdx.x - h * B;
+  const float g = upstream[h];
+  const size_t o = (size_t)b * ld + hd.col0[h];
+  for (int c = threadIdx.x; c < hd.ncls[h]; c += 256) out[o + c] = dsc[o + c] * g;
+}
+
 extern "C" {
+
+int tbn_dropout_fwd(const float* x, const float* rnd, float p, float* y, float* mask, size_t count, void* stream) {
+  TBN_REQUIRE(x && rnd && y && mask && p >= 0.f && p < 1.f, "dropout_fwd: bad argument (p = %g)", (double)p);
+  TBN_KLAUNCH(dropout_fwd_kernel, dim3(ew_grid(count)), dim3(256), 0, (hipStream_t)stream, x, rnd, p, 1.f / (1.f - p), y,
+              mask, count);
+  TBN_CHECK_LAUNCH("dropout_fwd");
+  return TBN_OK;
+}
+
+int tbn_ce_heads_fwd(const float* scores, int ld, int batch, int num_heads, const int* col0, const int* ncls,
+                     const long long* const* labels, float* rowloss, float* loss, float* dscores, void* stream) {
+  TBN_REQUIRE(scores && col0 && ncls && labels && rowloss && loss && dscores, "ce_heads_fwd: null argument");
+  TBN_REQUIRE(num_heads >= 1 && num_heads <= 4 && batch >= 1, "ce_heads_fwd: 1..4 heads, batch >= 1");
+  CeHeads hd;
+  hd.n = num_heads;
+  for (int h = 0; h < num_heads; ++h) {
+    TBN_REQUIRE(col0[h] >= 0 && ncls[h] >= 1 && col0[h] + ncls[h] <= ld && labels[h] != nullptr,
+                "ce_heads_fwd: head %d covers columns [%d, %d) of %d", h, col0[h], col0[h] + ncls[h], ld);
+    hd.col0[h] = col0[h];
+    hd.ncls[h] = ncls[h];
+    hd.label[h] = labels[h];
+  }
+  TBN_KLAUNCH(ce_heads_fwd_kernel, dim3(num_heads * batch), dim3(256), 0, (hipStream_t)stream, scores, ld, hd, batch, rowloss,
+              dscores);
+  TBN_CHECK_LAUNCH("ce_heads_fwd");
+  TBN_KLAUNCH(ce_heads_mean_kernel, dim3(num_heads), dim3(64), 0, (hipStream_t)stream, rowloss, batch, num_heads, loss);
+  TBN_CHECK_LAUNCH("ce_heads_mean");
+  return TBN_OK;
+}
+
+int tbn_ce_heads_bwd(const float* dscores, int ld, int batch, int num_heads, const int* col0, const int* ncls,
+                     const float* upstream, float* out, void* stream) {
+  TBN_REQUIRE(dscores && col0 && ncls && upstream && out && num_heads >= 1 && num_heads <= 4 && batch >= 1,
+              "ce_heads_bwd: bad argument");
+  CeHeads hd;
+  hd.n = num_heads;
+  for (int h = 0; h < num_heads; ++h) {
+    TBN_REQUIRE(col0[h] >= 0 && ncls[h] >= 1 && col0[h] + ncls[h] <= ld, "ce_heads_bwd: head %d out of range", h);
+    hd.col0[h] = col0[h];
+    hd.ncls[h] = ncls[h];
+    hd.label[h] = nullptr;
+  }
+  TBN_KLAUNCH(ce_heads_bwd_kernel, dim3(num_heads * batch), dim3(256), 0, (hipStream_t)stream, dscores, ld, hd, batch,
+              upstream, out);
+  TBN_CHECK_LAUNCH("ce_heads_bwd");
+  return TBN_OK;
+}
 
 int tbn_pe_concat_fwd(const float* feat, int feat_ld, const float* pe, float* out, int out_ld, int r, int t, int c,
                       int pe_dim, void* stream) {

@@ -290,12 +290,115 @@ class _MulMaskFn(torch.autograd.Function):
         return dx, None
 
 
+class _DropoutFn(torch.autograd.Function):
+    """y = x * mask, mask = rnd >= p ? 1 / (1 - p) : 0 in ONE launch (was: compare, cast, scale, multiply)"""
+
+    @staticmethod
+    def forward(ctx, x, rnd, p):
+        _need_cuda(x, "dropout")
+        x = _f32c(x)
+        y = torch.empty_like(x)
+        mask = torch.empty_like(x)
+        call("tbn_dropout_fwd", ptr(x), ptr(rnd), float(p), ptr(y), ptr(mask), x.numel(), stream_ptr())
+        ctx.save_for_backward(mask)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (mask,) = ctx.saved_tensors
+        dy = _f32c(dy)
+        dx = torch.empty_like(dy)
+        call("tbn_mul_mask", ptr(dy), ptr(mask), ptr(dx), dy.numel(), stream_ptr())
+        return dx, None, None
+
+
 def dropout(x, p, training):
-    """nn.Dropout: the keep/scale mask comes from torch's RNG (plumbing), the multiply is HIP."""
+    """nn.Dropout: the uniform draw comes from torch's RNG (plumbing), mask and multiply are one HIP launch."""
     if not training or p <= 0:
         return x
-    mask = (torch.rand_like(x) >= p).to(x.dtype) / (1.0 - p)
-    return _MulMaskFn.apply(x, mask)
+    return _DropoutFn.apply(x, torch.rand_like(x), p)
+
+
+class _CatPadFn(torch.autograd.Function):
+    """rows of several parameters stacked and zero-padded to a multiple of `mult` rows -- the classifier's per-key
+    nn.Linear weights / biases as ONE GEMM operand (reference model.py:365-386 keeps one nn.Linear per key).  The stacked
+    copy lives in `cache` and is rebuilt only when a parameter changed (its autograd version counter: the optimiser's
+    in-place update bumps it); backward hands each parameter its rows of the gradient."""
+
+    @staticmethod
+    def forward(ctx, cache, mult, *params):
+        key = tuple((p.data_ptr(), p._version) for p in params)
+        rows = [p.shape[0] for p in params]
+        if cache.get("key") != key:
+            n = sum(rows)
+            npad = (n + mult - 1) // mult * mult
+            buf = cache.get("buf")
+            shape = (npad,) + tuple(params[0].shape[1:])
+            if buf is None or tuple(buf.shape) != shape or buf.device != params[0].device:
+                buf = cache["buf"] = torch.zeros(shape, device=params[0].device, dtype=params[0].dtype)
+            o = 0
+            for p, r in zip(params, rows):
+                buf[o:o + r].copy_(p.detach())
+                o += r
+            cache["key"] = key
+        ctx.rows = rows
+        return cache["buf"].detach()     # a fresh tensor object per call (shares storage and version counter with the cache)
+
+    @staticmethod
+    def backward(ctx, g):
+        out, o = [], 0
+        for r in ctx.rows:
+            out.append(g[o:o + r])
+            o += r
+        return (None, None) + tuple(out)
+
+
+def cat_pad_rows(cache, mult, *params):
+    return _CatPadFn.apply(cache, mult, *params)
+
+
+class _CeHeadsFn(torch.autograd.Function):
+    """mean cross entropy of H heads over one (B, ld) score matrix -> H scalar losses (tbn_ce_heads_fwd / _bwd)"""
+
+    @staticmethod
+    def forward(ctx, scores, heads, *labels):
+        _need_cuda(scores, "cross_entropy_heads")
+        import ctypes as C
+        B, ld = scores.shape
+        H = len(heads)
+        col0 = (C.c_int * H)(*[h[0] for h in heads])
+        ncls = (C.c_int * H)(*[h[1] for h in heads])
+        labs = [l.contiguous() for l in labels]
+        for l in labs:
+            if l.dtype != torch.int64 or not l.is_cuda or l.numel() != B:
+                raise TbnHipError("cross_entropy_heads: labels must be int64 GPU tensors of the batch size")
+        lptr = (C.c_void_p * H)(*[l.data_ptr() for l in labs])
+        rowloss = torch.empty(H * B, device=scores.device, dtype=torch.float32)
+        loss = torch.empty(H, device=scores.device, dtype=torch.float32)
+        dsc = torch.zeros_like(scores)
+        call("tbn_ce_heads_fwd", ptr(scores), ld, B, H, col0, ncls, lptr, ptr(rowloss), ptr(loss), ptr(dsc), stream_ptr())
+        ctx.heads = heads
+        ctx.save_for_backward(dsc)
+        return tuple(loss[h] for h in range(H))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        import ctypes as C
+        (dsc,) = ctx.saved_tensors
+        B, ld = dsc.shape
+        H = len(ctx.heads)
+        up = torch.stack([g if g is not None else dsc.new_zeros(()) for g in grads]).float().contiguous()
+        col0 = (C.c_int * H)(*[h[0] for h in ctx.heads])
+        ncls = (C.c_int * H)(*[h[1] for h in ctx.heads])
+        out = torch.zeros_like(dsc)
+        call("tbn_ce_heads_bwd", ptr(dsc), ld, B, H, col0, ncls, ptr(up), ptr(out), stream_ptr())
+        return (out, None) + (None,) * H
+
+
+def cross_entropy_heads(scores, heads, labels):
+    """scores (B, ld) contiguous; heads = [(first column, classes)]; labels = [int64 (B,)] -> tuple of 0-dim losses
+    (nn.CrossEntropyLoss() with its defaults, per head).  Labels outside [0, classes) give NaN, not an error."""
+    return _CeHeadsFn.apply(scores, tuple(heads), *labels)
 
 
 def dropout_mask(shape, p, training, device):

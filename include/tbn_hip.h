@@ -333,6 +333,19 @@ int tbn_weighted_sum_bwd(const float* dout, int dout_ld, const float* w, float* 
 /* temporal consensus (model.py:178-203): out[b][c] = mean_n x[b*n+i][c] */
 int tbn_segment_mean_fwd(const float* x, float* out, int b, int n, int c, void* stream);
 int tbn_segment_mean_bwd(const float* dout, float* dx, int b, int n, int c, void* stream);
+/* nn.Dropout(p) of the fusion layer (reference model.py:352-362) from a caller-drawn uniform tensor `rnd` in [0, 1):
+ * mask = rnd >= p ? 1 / (1 - p) : 0, y = x * mask, both written (the mask is what backward multiplies by: tbn_mul_mask) */
+int tbn_dropout_fwd(const float* x, const float* rnd, float p, float* y, float* mask, size_t count, void* stream);
+/* The cross-entropy losses of up to 4 classification heads that share ONE score matrix (reference model.py:272-279: one
+ * nn.CrossEntropyLoss(mean) per class key, `verb` and `noun`): head h owns columns [col0[h], col0[h] + ncls[h]) of
+ * scores (batch, ld), labels[h] = int64[batch] device pointers (host array of them).  Writes loss[h] (device, mean over
+ * the batch, fixed summation order), rowloss (scratch, num_heads * batch floats) and dscores (batch, ld) =
+ * d(sum_h loss[h]) / d(scores) for the heads' columns (other columns untouched).  tbn_ce_heads_bwd scales a head's columns
+ * of dscores by upstream[h] (device) into `out` (may alias dscores): the backward for arbitrary per-head weights. */
+int tbn_ce_heads_fwd(const float* scores, int ld, int batch, int num_heads, const int* col0, const int* ncls,
+                     const long long* const* labels, float* rowloss, float* loss, float* dscores, void* stream);
+int tbn_ce_heads_bwd(const float* dscores, int ld, int batch, int num_heads, const int* col0, const int* ncls,
+                     const float* upstream, float* out, void* stream);
 /* y = x * mask (dropout with a caller-generated keep/scale mask); in place allowed */
 int tbn_mul_mask(const float* x, const float* mask, float* y, size_t count, void* stream);
 /* dx = dy * [y > 0] (* mask if non-NULL): backward of Linear->ReLU->Dropout (model.py:337-362) */

@@ -580,3 +580,91 @@ def test_log_mel_spectrogram_vs_oracle():
         want = log_mel_spectrogram(wave[i].numpy())
         assert abs(got[i].max()) < 1e-5 and got[i].min() >= -80.0 - 1e-3
         assert np.abs(got[i] - want).max() < 2e-3, i          # dB
+
+
+@pytest.mark.parametrize("B,heads", [(32, [(0, 125), (125, 352)]), (1, [(0, 7)]), (5, [(32, 1000), (0, 3), (3, 29)]),
+                                     (257, [(0, 125), (125, 352), (480, 2), (500, 300)])])
+def test_cross_entropy_heads_vs_torch(B, heads):
+    """ops.cross_entropy_heads (reference model.py:272-279: one nn.CrossEntropyLoss per class key over its logits) against
+    torch's own cross entropy in fp64: every head's loss and, with a different upstream weight per head, the gradient with
+    respect to the shared score matrix (columns outside every head must stay exactly zero)."""
+    from attention_based_tbn_amd import ops
+    g = torch.Generator().manual_seed(B)
+    ld = max(o + n for o, n in heads) + 5
+    ld = (ld + 31) // 32 * 32
+    scores = (torch.randn(B, ld, generator=g) * 4).to(DEV).requires_grad_()
+    labels = [torch.randint(0, n, (B,), generator=g).to(DEV) for _, n in heads]
+    wts = [0.5 + 0.7 * i for i in range(len(heads))]
+    losses = ops.cross_entropy_heads(scores, heads, labels)
+    sum(w * l for w, l in zip(wts, losses)).backward()
+    ref = scores.detach().double().cpu().requires_grad_()
+    rl = [F.cross_entropy(ref[:, o:o + n], lab.cpu()) for (o, n), lab in zip(heads, labels)]
+    sum(w * l for w, l in zip(wts, rl)).backward()
+    for a, b in zip(losses, rl):
+        assert abs(float(a) - float(b)) <= 2e-6 * max(1.0, abs(float(b))), (float(a), float(b))
+    got, want = scores.grad.double().cpu(), ref.grad
+    assert float((got - want).abs().max()) <= 1e-6 * float(want.abs().max()), float((got - want).abs().max())
+    covered = torch.zeros(ld, dtype=torch.bool)
+    for o, n in heads:
+        covered[o:o + n] = True
+    assert float(got[:, ~covered].abs().max()) == 0.0 if (~covered).any() else True
+    # an out-of-range label poisons that head's loss (no out-of-bounds read, no silent value)
+    bad = [l.clone() for l in labels]
+    bad[0][0] = heads[0][1]
+    out = ops.cross_entropy_heads(scores.detach(), heads, bad)
+    assert math.isnan(float(out[0])) and all(math.isfinite(float(x)) for x in out[1:])
+
+
+def test_fused_dropout_matches_the_mask_rule():
+    """tbn_dropout_fwd: mask = rnd >= p ? 1 / (1 - p) : 0, y = x * mask in one launch; backward multiplies by the mask"""
+    from attention_based_tbn_amd import ops
+    torch.manual_seed(5)
+    x = torch.randn(96, 512, device=DEV, requires_grad=True)
+    torch.manual_seed(11)
+    y = ops.dropout(x, 0.5, True)
+    torch.manual_seed(11)
+    rnd = torch.rand_like(x)
+    mask = (rnd >= 0.5).float() / 0.5
+    assert torch.equal(y.detach(), x.detach() * mask)
+    y.backward(torch.ones_like(y) * 3.0)
+    assert torch.equal(x.grad, mask * 3.0)
+    assert ops.dropout(x, 0.5, False) is x and ops.dropout(x, 0.0, True) is x
+    kept = float((y != 0).float().mean())
+    assert 0.45 < kept < 0.55
+
+
+def test_classifier_weight_cache_follows_parameter_updates():
+    """Classifier (reference model.py:365-386): the stacked / padded weight copy is cached between steps and must be
+    rebuilt when a head's parameters change in place (optimiser step) or are replaced (load_state_dict); gradients reach
+    every head's own nn.Linear parameters"""
+    from attention_based_tbn_amd.core.models.model import Classifier
+    torch.manual_seed(0)
+    clf = Classifier({"verb": 125, "noun": 352}, 512).to(DEV)
+    x = torch.randn(6, 512, device=DEV)
+
+    def ref():
+        return torch.cat([F.linear(x.double(), clf.verb.weight.double(), clf.verb.bias.double()),
+                          F.linear(x.double(), clf.noun.weight.double(), clf.noun.bias.double())], 1)
+
+    def got():
+        out = clf(x)
+        return torch.cat([out["verb"], out["noun"]], 1), out
+
+    a, out = got()
+    assert float((a.double() - ref()).abs().max()) < 1e-5
+    assert out["verb"]._tbn_head[1:] == (0, 125) and out["noun"]._tbn_head[1:] == (125, 352)
+    buf0 = clf._wcache["buf"]
+    got()
+    assert clf._wcache["buf"] is buf0                      # unchanged parameters: no rebuild
+    (out["verb"].sum() + 2 * out["noun"].sum()).backward()
+    assert clf.verb.weight.grad.shape == (125, 512) and clf.noun.bias.grad.shape == (352,)
+    assert torch.allclose(clf.noun.bias.grad, torch.full((352,), 12.0, device=DEV))
+    with torch.no_grad():
+        clf.noun.weight.add_(0.25)                         # what an optimiser step does
+        clf.verb.bias.mul_(0).add_(1.0)
+    b, _ = got()
+    assert float((b.double() - ref()).abs().max()) < 1e-5 and not torch.equal(a, b)
+    sd = {k: torch.randn_like(v) * 0.01 for k, v in clf.state_dict().items()}
+    clf.load_state_dict(sd)
+    c, _ = got()
+    assert float((c.double() - ref()).abs().max()) < 1e-5
