@@ -126,8 +126,15 @@ class _BackboneFn(torch.autograd.Function):
         call("tbn_backbone_forward", plan.handle, int(training), ptr(x), C.byref(prm), ptr(ws), ws.numel(),
              C.byref(feat_ptr), st)
         N, H, W, Cc = plan.out_shape
-        out = torch.empty((N, W, Cc) if freq_only else (N, Cc), device=x.device, dtype=torch.float32)
-        call("tbn_spatial_mean_fwd", feat_ptr.value, Cc, ptr(out), Cc, N, H, W, Cc, int(freq_only), st)
+        slot = module._out_slot
+        module._out_slot = None
+        if (not freq_only and slot is not None and tuple(slot.shape) == (N, Cc) and slot.stride(1) == 1 and slot.is_cuda
+                and slot.device == x.device and slot.dtype == torch.float32):
+            out = slot           # the caller's column range of a wider buffer (TBNModel: the concatenated features)
+        else:
+            out = torch.empty((N, W, Cc) if freq_only else (N, Cc), device=x.device, dtype=torch.float32)
+        call("tbn_spatial_mean_fwd", feat_ptr.value, Cc, ptr(out), Cc if freq_only else out.stride(0), N, H, W, Cc,
+             int(freq_only), st)
         if training:
             module.num_batches_tracked += 1
         if need_grad:
@@ -151,9 +158,11 @@ class _BackboneFn(torch.autograd.Function):
         plan, ws, module = ctx.plan, ctx.ws, ctx.module
         N, H, W, Cc = plan.out_shape
         st = stream_ptr()
-        dout = dout.contiguous()
+        if ctx.freq_only or dout.dim() != 2 or dout.stride(1) != 1 or dout.dtype != torch.float32:
+            dout = dout.contiguous().float()
+        dout_ld = Cc if ctx.freq_only else dout.stride(0)      # a column range of the fusion layer's input gradient: read in place
         dfeat = torch.empty(plan.out_shape, device=dout.device, dtype=torch.float32)
-        call("tbn_spatial_mean_bwd", ptr(dout), Cc, ptr(dfeat), Cc, N, H, W, Cc, int(ctx.freq_only), st)
+        call("tbn_spatial_mean_bwd", ptr(dout), dout_ld, ptr(dfeat), Cc, N, H, W, Cc, int(ctx.freq_only), st)
         dw = torch.empty_like(weight)
         db = torch.empty_like(bias)
         need = ctx.needs_input_grad
@@ -204,6 +213,7 @@ class BNInception(nn.Module):
         # GEMM launch (include/tbn_hip.h TBN_BACKBONE_RIDERS); one-chain program only -- the engine ignores the flag in
         # branch mode -- and bit-identical to the stand-alone passes
         self.use_riders = True
+        self._out_slot = None       # set by TBNModel for one forward: where the pooled (frames, 1024) feature is to be written
         self.plan_sync = None       # data parallel: object with is_source() / broadcast(blob, device) (DataParallel.PlanSync)
         self._plans = OrderedDict()
         # layer table from the engine (needs the library, not a GPU)

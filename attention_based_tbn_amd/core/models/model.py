@@ -21,6 +21,36 @@ from .attention import MultiheadedAttention, PositionalEncoding, PrototypeAttent
 from .bn_inception import bninception
 
 
+class _ArenaCatFn(torch.autograd.Function):
+    """the concatenation of features that ALREADY sit side by side in `arena`: no copy forward, column views backward"""
+
+    @staticmethod
+    def forward(ctx, arena, *feats):
+        ctx.widths = [f.shape[1] for f in feats]
+        return arena.detach()
+
+    @staticmethod
+    def backward(ctx, g):
+        out, o = [], 0
+        for w in ctx.widths:
+            out.append(g[:, o:o + w])
+            o += w
+        return (None,) + tuple(out)
+
+
+def _concat_features(arena, features):
+    """torch.cat(features, dim=1) (reference model.py:250) -- free when every feature is its column range of `arena`"""
+    if arena is not None and sum(f.shape[1] for f in features) == arena.shape[1]:
+        o, ok = 0, True
+        for f in features:
+            ok = ok and (f.dim() == 2 and f.shape[0] == arena.shape[0] and f.stride() == (arena.shape[1], 1)
+                         and f.data_ptr() == arena.data_ptr() + 4 * o and f.dtype == arena.dtype)
+            o += f.shape[1]
+        if ok:
+            return _ArenaCatFn.apply(arena, *features)
+    return torch.cat(features, dim=1)
+
+
 class _PadColsFn(torch.autograd.Function):
     """Conv1d(k=1) weight (N, K, 1) as a GEMM operand (N, kp) with K zero-padded to kp columns; cached until the parameter
     changes (its version counter), like ops.cat_pad_rows"""
@@ -194,6 +224,23 @@ class TBNModel(nn.Module):
 
     def _run_backbones(self, input):
         """raw backbone outputs per modality: (R,1024), or (R,T,1024) for attended audio"""
+        # mid-level fusion concatenates the modality features (reference model.py:250): every backbone writes its pooled
+        # feature straight into its column range of ONE (R, 1024 M) buffer -- the torch.cat copy and the three slice copies
+        # of its backward are gone (forward() hands the buffer to the fusion layer when every feature really sits in it)
+        self._arena = None
+        first_in = input[self.modality[0]]
+        if len(self.modality) > 1 and first_in.is_cuda:
+            R = first_in.shape[0] * first_in.shape[1]
+            self._arena = torch.empty(R, 1024 * len(self.modality), device=first_in.device, dtype=torch.float32)
+            for i, m in enumerate(self.modality):
+                getattr(self, "Base_{}".format(m))._out_slot = self._arena[:, 1024 * i:1024 * (i + 1)]
+        try:
+            return self._run_backbones_inner(input)
+        finally:
+            for m in self.modality:
+                getattr(self, "Base_{}".format(m))._out_slot = None
+
+    def _run_backbones_inner(self, input):
         def run(m):
             b, n, c, h, w = input[m].shape
             base = getattr(self, "Base_{}".format(m))
@@ -256,7 +303,11 @@ class TBNModel(nn.Module):
             else:
                 feature = raw_all[m]
             features.extend([feature])
-        features = torch.cat(features, dim=1) if len(features) > 1 else features[0]
+        if len(features) > 1:
+            features = _concat_features(self._arena, features)
+        else:
+            features = features[0]
+        self._arena = None
 
         if len(self.modality) > 1:
             features = self.fusion(features)

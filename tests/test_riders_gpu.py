@@ -23,7 +23,7 @@ sys.path.insert(0, sys.argv[1])
 from attention_based_tbn_amd._lib import lib
 from attention_based_tbn_amd.core.models.bn_inception import BNInception
 DEV = torch.device("cuda")
-for cin, N, H, W in ((3, 6, 224, 224), (1, 5, 128, 256), (10, 3, 96, 96), (3, 24, 112, 112)):
+for cin, N, H, W in ((3, 6, 224, 224), (1, 5, 128, 256), (10, 3, 96, 96), (3, 24, 128, 128)):
     torch.manual_seed(cin + N)
     net = BNInception(1000, cin).to(DEV)
     with torch.no_grad():
