@@ -123,4 +123,10 @@ class FusedSGD(torch.optim.Optimizer):
             for a, n in _chunks(ents):
                 call("tbn_opt_sgd_step", a, n, float(group["lr"]), mom, float(group["weight_decay"]), ptr(gscale),
                      stream_ptr())
+            # the kernel wrote the parameters (and momentum buffers) through raw pointers: tell autograd, as an in-place
+            # torch op would have -- saved-tensor checks and every cache keyed on `_version` (the classifier's stacked
+            # weight copy, core/models/model.py) rely on the counter
+            torch.autograd.graph.increment_version(params)
+            if bufs is not None:
+                torch.autograd.graph.increment_version(bufs)
         return loss

@@ -668,3 +668,15 @@ def test_classifier_weight_cache_follows_parameter_updates():
     clf.load_state_dict(sd)
     c, _ = got()
     assert float((c.double() - ref()).abs().max()) < 1e-5
+    # the fused optimiser writes the parameters through raw pointers: it must bump their version counters like an in-place
+    # torch op, or the cached copy goes stale (found by the RCCL world-size-1 test in round 5)
+    from attention_based_tbn_amd.core.utils import FusedSGD
+    opt = FusedSGD(clf.parameters(), 0.5, momentum=0.9)
+    v0 = clf.noun.weight._version
+    _, out = got()
+    clf.zero_grad(set_to_none=True)
+    (out["verb"].square().sum() + out["noun"].sum()).backward()
+    opt.step()
+    assert clf.noun.weight._version > v0
+    d, _ = got()
+    assert float((d.double() - ref()).abs().max()) < 1e-5 and not torch.equal(c, d)
