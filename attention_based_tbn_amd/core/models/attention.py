@@ -45,7 +45,15 @@ class PositionalEncoding(nn.Module):
         return ops.pe_concat(seq, self.pe[0], out_ld)
 
     def forward(self, x):
-        """reference layout: (R, C, 1, T) -> (R, C + dim, T)"""
+        """reference layout: (R, C, 1, T) -> (R, C + dim, T); `encoding_type="add"` (unused by TBNModel, reference
+        attention.py:38-39): x + pe with the reference's own broadcasting rule -- it needs C == dim_size and T == max_len and
+        fails like the reference otherwise -- one elementwise torch-ROCm add, there is nothing to accelerate"""
+        if self.encoding_type == "add":
+            x = x.squeeze(2)
+            if not x.is_cuda:
+                raise ops.TbnHipError("PositionalEncoding: tensor is on the CPU; the TBN hot path only runs on an MI355X")
+            out = x + self.pe[: x.size(0), :]
+            return ops.dropout(out, self.dropout, self.training) if self.dropout > 0 else out
         seq = x.squeeze(2).transpose(1, 2)
         c = seq.shape[2] + self.dim_size
         out = self.forward_sequence(seq, (c + 31) // 32 * 32)[:, :, :c]
@@ -87,13 +95,32 @@ class MultiheadedAttention(nn.Module):
         return ops.linear(ctx, a.out_proj.weight, a.out_proj.bias), w
 
     def forward(self, query, key, value):
-        """reference layout: query (1, R, E), key = value (T, R, E) -> ((1, R, E), (R, 1, T))"""
-        if key is not value:
-            raise NotImplementedError("the HIP attention core implements the key-is-value case the TBN uses")
-        if query.shape[0] != 1:
-            raise NotImplementedError("the HIP attention core implements L_q = 1")
-        out, w = self.attend(query[0], key.transpose(0, 1).contiguous())
-        return out.unsqueeze(0), w.unsqueeze(1)
+        """reference layout: query (L, R, E), key / value (T, R, E) -> ((L, R, E), (R, L, T)) like
+        torch.nn.MultiheadAttention (reference attention.py:48-57).  The TBN's own call -- ONE query per sample, key is value
+        (model.py:231-237) -- runs on the wavefront-reduction kernel; any other call shape takes the general path: the three
+        projections and the output projection on the HIP GEMM, the (tiny) score / softmax / weighted-sum core as batched
+        torch-ROCm ops."""
+        if key is value and query.shape[0] == 1:
+            out, w = self.attend(query[0], key.transpose(0, 1).contiguous())
+            return out.unsqueeze(0), w.unsqueeze(1)
+        a = self.attention_layer
+        E, H = a.embed_dim, a.num_heads
+        L, R, _ = query.shape
+        T = key.shape[0]
+        assert key.shape[1] == R and value.shape[:2] == key.shape[:2] and query.shape[2] == E
+        d = E // H
+        q = ops.linear(query.reshape(L * R, E), a.in_proj_weight[:E], a.in_proj_bias[:E]) * (float(d) ** -0.5)
+        k = ops.linear(key.reshape(T * R, E), a.in_proj_weight[E:2 * E], a.in_proj_bias[E:2 * E])
+        v = ops.linear(value.reshape(T * R, E), a.in_proj_weight[2 * E:], a.in_proj_bias[2 * E:])
+        q = q.view(L, R * H, d).transpose(0, 1)              # (R H, L, d): torch's head layout
+        k = k.view(T, R * H, d).transpose(0, 1)
+        v = v.view(T, R * H, d).transpose(0, 1)
+        p = torch.softmax(torch.bmm(q, k.transpose(1, 2)), dim=-1)      # (R H, L, T)
+        if self.training and a.dropout > 0:
+            p = F.dropout(p, p=a.dropout)
+        ctx = torch.bmm(p, v).transpose(0, 1).reshape(L * R, E)
+        out = ops.linear(ctx, a.out_proj.weight, a.out_proj.bias).view(L, R, E)
+        return out, p.view(R, H, L, T).mean(dim=1)
 
 
 class UniModalAttention(nn.Module):
