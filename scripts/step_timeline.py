@@ -49,7 +49,8 @@ def family(name):
                      ("bn_", "bn_other"), ("maxpool", "pool"), ("avgpool", "pool"),
                      ("pool", "pool"), ("opt_sgd", "optimizer"), ("opt_", "optimizer"), ("clip", "optimizer"), ("sqnorm", "optimizer"),
                      ("nchw_to_", "layout"), ("pack_stem", "layout"), ("unpack_stem", "layout"),
-                     ("spatial_mean", "heads"), ("segment_mean", "heads"), ("mul_mask", "heads"), ("Cijk", "heads"),
+                     ("spatial_mean", "heads"), ("segment_mean", "heads"), ("mul_mask", "heads"), ("dropout_fwd", "heads"), ("ce_heads", "heads"),
+                     ("relu_mask_bwd", "heads"), ("colsum", "heads"), ("Cijk", "heads"),
                      ("gemm", "heads"), ("elementwise", "torch_ew"), ("CatArray", "torch_ew"), ("softmax", "torch_ew"),
                      ("nll_loss", "torch_ew"), ("reduce_kernel", "torch_ew"), ("ncclDevKernel", "rccl")):
         if key in n:
