@@ -622,7 +622,8 @@ def main():
     marks[args.steps].record()
     fence()
     dt = time.perf_counter() - t0
-    step_gpu_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    step_gpu_each = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
+    step_gpu_ms = sorted(step_gpu_each)
     exposed_ms = None
     if world > 1 and hasattr(model, "exposed_sync_ms"):
         e = model.exposed_sync_ms()
@@ -706,7 +707,9 @@ def main():
             # GPU time of each timed step (events at the step boundaries of rank 0's compute stream): a clock ramp or a
             # straggler step shows up here, not in the mean
             "step_gpu_ms": {"median": round(step_gpu_ms[len(step_gpu_ms) // 2], 3), "min": round(step_gpu_ms[0], 3),
-                            "max": round(step_gpu_ms[-1], 3)},
+                            "max": round(step_gpu_ms[-1], 3), "max_at_step": step_gpu_each.index(step_gpu_ms[-1]),
+                            "slowest_five": [[i, round(t, 3)] for t, i in sorted(((t, i) for i, t in enumerate(step_gpu_each)),
+                                                                                  reverse=True)[:5]]},
         }
         if world > 1:
             line["multi_gpu"] = {"dist_world_size": dist.get_world_size(), "cuda_device_count": torch.cuda.device_count(),
