@@ -561,8 +561,6 @@ def main():
 
     step()   # priming pass (plan creation + per-layer tile autotune happen on first use of a shape): never timed, and
              # not one of the W warm-up steps, so a small --warmup cannot push the autotuner into the timed region
-    for _ in range(args.warmup):
-        step()
     L = lib()
     L.tbn_profile_reset()
     box = box_identity(device, smi) if rank == 0 else None     # CPU / GPU names + a warm pure-MFMA burst: before the timed loop
@@ -590,6 +588,12 @@ def main():
         probe = {"bytes": nfl * 4, "ms": round(ms, 3), "algbw_GBps": round(algbw, 1),
                  "busbw_GBps": round(algbw * 2 * (world - 1) / world, 1), "backend": dist.get_backend()}
         del buf
+    # the W warm-up steps come LAST before the fence: the timed region then starts on a GPU that has just been running this
+    # very step.  (Round 5: with the box identity / MFMA calibration / all-reduce probe between warm-up and timed loop the
+    # GPU idled for tens of milliseconds first and timed step 0 was always the slowest -- 37.7 - 38.1 ms against a median of
+    # 35.6, the clock ramp of hardware finding 13 -- which a 20-step run pays as 0.3 %.)
+    for _ in range(args.warmup):
+        step()
     fence()
     if world > 1 and hasattr(model, "exposed_sync_ms"):
         model.exposed_sync_ms()     # drop the warm-up records
