@@ -602,6 +602,41 @@ def test_plan_export_import_round_trip_and_fingerprint():
         L.tbn_backbone_plan_destroy(h)
 
 
+def test_plan_cache_files_carry_one_modes_choices(tmp_path, monkeypatch):
+    """TBN_PLAN_CACHE (opt-in): a process writes the choices it tuned for one (problem, mode); a later plan of the same
+    problem adopts exactly that mode's fields and keeps the other mode's; no variable, a missing file, another library
+    version or another problem: nothing is loaded.  Host only."""
+    import ctypes as C
+    import struct
+    from attention_based_tbn_amd._lib import lib
+    from attention_based_tbn_amd.core.models.bn_inception import _Plan
+    a = _Plan(3, 4, 96, 96)
+    assert a.load_cached(3, True) is False                      # variable not set
+    monkeypatch.setenv("TBN_PLAN_CACHE", str(tmp_path / "plans"))
+    assert a.load_cached(3, True) is False                      # no file yet
+    ints = list(struct.unpack("%di" % (len(a.export_choices()) // 4), a.export_choices()))
+    g = next(i for i in range(44) if ints[8 + 26 * i + 8 + 3] == 0 and i > 2)   # any non-stem GEMM
+    base = 8 + 26 * g
+    ints[base + 8:base + 12] = [2, 2, 2, 0]                     # training forward: <2,2>, 2 LDS stages
+    ints[base:base + 4] = [1, 3, 1, 0]                          # eval forward: <1,3>, 1 stage
+    a.import_choices(struct.pack("%di" % len(ints), *ints))
+    fp_a = a.fingerprint()
+    a.store_cached(3, True)
+    files = os.listdir(tmp_path / "plans")
+    assert len(files) == 1 and files[0] == "tbnplan_v%d_c3_f4_96x96_train.bin" % lib().tbn_version()
+    b = _Plan(3, 4, 96, 96)
+    fp_fresh = b.fingerprint()
+    assert b.load_cached(3, False) is False                     # no eval file
+    assert b.load_cached(3, True) is True
+    got = list(struct.unpack("%di" % len(ints), b.export_choices()))
+    assert got[base + 8:base + 12] == [2, 2, 2, 0]              # the training-mode choice came over ...
+    assert got[base:base + 4] != [1, 3, 1, 0]                   # ... the eval-mode one did not (a training file)
+    assert b.fingerprint() not in (fp_fresh, fp_a)
+    a.store_cached(3, False)
+    assert b.load_cached(3, False) is True and b.fingerprint() == fp_a
+    assert _Plan(3, 5, 96, 96).load_cached(3, True) is False    # another problem: another file name
+
+
 def test_isa_wait_scan_flags_a_wait_right_behind_its_load(tmp_path, capsys):
     """scripts/isa_wait_scan.py on a synthetic listing: a loop that waits vmcnt(0) two MFMAs behind a load is reported as
     tight, the same loop with the load issued a whole trip earlier (vmcnt(1)) is not"""
