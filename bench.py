@@ -237,7 +237,7 @@ def query_rocm_smi():
 def box_identity(device, smi=None):
     """What this line was measured ON, so that two lines from two boxes of a pool explain their own gap: CPU model, GPU
     name, rocm-smi's power cap / clocks when the tool answers, and a warm pure-fp32-MFMA burst (tbn_diag_mfma_burst:
-    registers only, no memory traffic) timed after 30 ms of the same load -- a cold burst runs ~12 % slow (DESIGN.md finding
+    registers only, no memory traffic) timed after 30 ms of the same load -- a cold burst runs ~12 % slow (profiles/HISTORY.md finding
     13) -- as TFLOP/s and as a fraction of the 157.3 the roofline is priced in."""
     from attention_based_tbn_amd._lib import call, ptr, stream_ptr
     out = dict(host_cpu())

@@ -1,7 +1,7 @@
 """Per-tile timing of the three forward implicit-GEMM variants (register-staged generic kernel, LDS-halo 3x3 kernel,
 LDS-DMA staging) on one conv shape, BN-statistics epilogue (the training forward): us and TFLOP/s per (MT, NT).
 REPS / WARM (environment): timed / untimed launches per cell, default 10 / 2 = a cold 1-ms burst; REPS=100 WARM=150 times
-with the shader clock warm (DESIGN.md finding 13: ~12 % faster, and the only setting in which 1 % differences resolve)."""
+with the shader clock warm (profiles/HISTORY.md finding 13: ~12 % faster, and the only setting in which 1 % differences resolve)."""
 import sys, os, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from attention_based_tbn_amd._lib import call, ptr, lib
