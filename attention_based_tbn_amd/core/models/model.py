@@ -379,9 +379,15 @@ class TBNModel(nn.Module):
                 loss["contrast"] = criterion["contrast"](wts)
                 loss["total"] += contrast_multiplier * loss["contrast"]
             if att.use_entropy:
-                loss["entropy"] = Categorical(probs=wts + 1e-6).entropy().mean()
-                if self.training and entropy_multiplier > 0 and loss["entropy"] < att.entropy_thresh:
-                    entropy_multiplier = 0
+                # validate_args=False: torch 1.4 (the reference's, install/requirements.txt:12) does not validate distribution
+                # arguments; current torch does by default, with a `.all()` the HOST reads -- a device synchronisation in
+                # the middle of every step (round 5: the host ran in lock-step with the GPU in config 3, so one 80-ms Python
+                # GC pause showed up as a 130-ms step)
+                loss["entropy"] = Categorical(probs=wts + 1e-6, validate_args=False).entropy().mean()
+                if self.training and entropy_multiplier > 0:
+                    # reference model.py:327-329: `if loss["entropy"] < entropy_thresh: entropy_multiplier = 0` -- the same
+                    # switch-off as a device-side factor (a Python `if` on a GPU tensor is a host synchronisation)
+                    entropy_multiplier = entropy_multiplier * (loss["entropy"].detach() >= att.entropy_thresh).to(loss["entropy"].dtype)
                 loss["total"] += entropy_multiplier * loss["entropy"]
         return loss, batch_size
 
