@@ -13,6 +13,7 @@ inputs already resident in HBM.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import ctypes as C
+import gc
 import json
 import os
 import sys
@@ -592,6 +593,10 @@ def main():
     # very step.  (Round 5: with the box identity / MFMA calibration / all-reduce probe between warm-up and timed loop the
     # GPU idled for tens of milliseconds first and timed step 0 was always the slowest -- 37.7 - 38.1 ms against a median of
     # 35.6, the clock ramp of hardware finding 13 -- which a 20-step run pays as 0.3 %.)
+    # host hygiene first: everything built so far (modules, plans, autograd plumbing) moves to the permanent generation, so a
+    # generation-2 collection inside the timed loop has little to walk (an 80-ms pause was measured in config 3)
+    gc.collect()
+    gc.freeze()
     for _ in range(args.warmup):
         step()
     fence()
