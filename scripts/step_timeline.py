@@ -94,6 +94,23 @@ cnt = defaultdict(int)
 for s, e, n, q in step:
     tot[family(n)] += e - s
     cnt[family(n)] += 1
+# how many conv GEMMs / how many kernels of any kind are in flight, by share of the wall time
+ev2 = []
+for s, e, n, q in step:
+    g = 1 if family(n) == "gemm" else 0
+    ev2.append((s, 1, g))
+    ev2.append((e, -1, -g))
+ev2.sort()
+ng = nk = 0
+by_g = defaultdict(int)
+by_k = defaultdict(int)
+last2 = t0
+for t, dk, dg in ev2:
+    by_g[min(ng, 4)] += t - last2
+    by_k[min(nk, 6)] += t - last2
+    nk += dk
+    ng += dg
+    last2 = t
 wall = t1 - t0
 print("step wall %.3f ms (first kernel -> last kernel end), to next step start %.3f ms, %d kernels" %
       (wall / 1e6, (t_next - t0) / 1e6, len(step)))
@@ -106,6 +123,8 @@ last_fwd_gemm = max((r[1] for r in step if r[0] < first_bwd and family(r[2]) == 
 last_bwd = max((r[1] for r in step if family(r[2]) in ("gemm", "bn_bwd_apply", "bn_bwd_stem_pooled", "splitk_reduce", "layout")), default=t1)
 print("phases: backbone forward %.3f ms | heads + loss (fwd+bwd) %.3f ms | backbone backward %.3f ms | tail (optimiser ...) %.3f ms"
       % ((last_fwd_gemm - t0) / 1e6, (first_bwd - last_fwd_gemm) / 1e6, (last_bwd - first_bwd) / 1e6, (t1 - last_bwd) / 1e6))
+print("conv GEMMs in flight (share of the wall time): " + "  ".join("%d%s: %.1f %%" % (k, "+" if k == 4 else "", 100.0 * v / (t1 - t0)) for k, v in sorted(by_g.items())))
+print("kernels in flight, any kind:                    " + "  ".join("%d%s: %.1f %%" % (k, "+" if k == 6 else "", 100.0 * v / (t1 - t0)) for k, v in sorted(by_k.items())))
 print("%-22s %8s %10s %12s %12s %10s" % ("family", "kernels", "sum ms", "hidden ms", "exposed ms", "alone ms"))
 for fam in sorted(tot, key=lambda k: -tot[k]):
     print("%-22s %8d %10.3f %12.3f %12.3f %10.3f" % (fam, cnt[fam], tot[fam] / 1e6, hidden[fam] / 1e6, exposed[fam] / 1e6,
