@@ -112,6 +112,26 @@ def _high_priority_modalities():
     return names
 
 
+def _shared_stream_map():
+    """A/B knob: TBN_SHARE_STREAM="Flow:RGB,..." lets a modality's backbone run on another modality's stream (fewer
+    concurrent chains).  Shipped: every modality its own stream (empty map); unknown names are ignored with a notice."""
+    raw = os.environ.get("TBN_SHARE_STREAM")
+    if not raw:
+        return {}
+    out = {}
+    for item in raw.split(","):
+        a, _, b = item.partition(":")
+        if a in ("RGB", "Flow", "Audio") and b in ("RGB", "Flow", "Audio") and a != b:
+            out[a] = b
+        elif not getattr(_shared_stream_map, "warned", False):
+            print(f"[tbn] experiment knob TBN_SHARE_STREAM={raw!r}: item {item!r} ignored", file=sys.stderr)
+            _shared_stream_map.warned = True
+    if out and not getattr(_shared_stream_map, "said", False):
+        print(f"[tbn] experiment knob TBN_SHARE_STREAM={raw} active: not the shipped configuration", file=sys.stderr)
+        _shared_stream_map.said = True
+    return out
+
+
 class TBNModel(nn.Module):
     IN_CHANNELS = {"RGB": 3, "Flow": 10, "Audio": 1}
 
@@ -252,7 +272,10 @@ class TBNModel(nn.Module):
             return {m: run(m) for m in self.modality}
         main = torch.cuda.current_stream()
         raw = {}
+        share = _shared_stream_map()        # A/B knob TBN_SHARE_STREAM="Flow:RGB": Flow's backbone runs on RGB's stream
         for m in self.modality:
+            if m in share and share[m] in self._streams:
+                self._streams[m] = self._streams[share[m]]
             st = self._streams.get(m)
             if st is None or st.device != first.device:
                 # the heaviest backbone (audio: 5.1 GFLOP per 256x256 frame against 4.1 / 4.6) gets the high-priority
