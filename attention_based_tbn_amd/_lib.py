@@ -28,9 +28,12 @@ class BackboneParams(C.Structure):
                 ("running_var", c_fp), ("momentum", c_f), ("eps", c_f), ("side_stream", c_fp), ("flags", c_i)]
 
 
+BUCKET_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_size_t, C.c_size_t)   # tbn_backbone_grads.bucket_cb(user, first_float, num_floats)
+
+
 class BackboneGrads(C.Structure):
     _fields_ = [("dweight", c_fp), ("dbias", c_fp), ("dgamma", c_fp), ("dbeta", c_fp), ("bn_grad_layers", c_i),
-                ("aux_stream", c_fp)]
+                ("aux_stream", c_fp), ("bucket_cb", BUCKET_CB), ("bucket_user", c_fp)]
 
 
 class ConvRed(C.Structure):

@@ -22,6 +22,8 @@ if os.environ.get("TBN_EXTRA_FLAGS"):         # experiments (same-box A/B of a -
     FLAGS += os.environ["TBN_EXTRA_FLAGS"].split()
 if os.environ.get("TBN_ABLATE") == "1":      # timing-ablation build for scripts/conv_ablate.py (never the shipped one)
     FLAGS.append("-DTBN_ABLATE=1")
+if os.environ.get("TBN_EXPERIMENT") == "1":  # A/B build: the only one whose library reads experiment knobs from the environment
+    FLAGS.append("-DTBN_EXPERIMENT=1")       # (tbn_common.h: tbn_env_int; the shipped library reads no environment variable)
 
 
 def _hipcc():
@@ -42,6 +44,8 @@ def _stale(target, deps):
 # TBN_BUILD_VARIANT=<name> objects and library go to scripts/ab/obj_<name>/ and scripts/ab/lib_<name>.so, and a run picks the
 # variant with TBN_LIB=<path> (attention_based_tbn_amd/_lib.py) -- nothing is copied over libtbn_hip.so (round-4 advisor)
 VARIANT = os.environ.get("TBN_BUILD_VARIANT")
+if not VARIANT and any(os.environ.get(k) == "1" for k in ("TBN_EXPERIMENT", "TBN_DIAG", "TBN_ABLATE")):
+    VARIANT = "exp" if os.environ.get("TBN_EXPERIMENT") == "1" else ("diag" if os.environ.get("TBN_DIAG") == "1" else "ablate")
 OBJDIR = CSRC
 if VARIANT:
     _ab = os.path.join(os.path.dirname(HERE), "scripts", "ab")

@@ -8,14 +8,34 @@ from ..._lib import call, lib, ptr, stream_ptr, TbnHipError
 
 
 def trim_audio_window(num_samples, frame_idx, audio_length, sampling_rate=24000, vid_fps=60):
-    """(start, length) of the `audio_length` s window centred on frame_idx / fps, clamped like the
-    reference (dataset.py:439-451).  The clip is assumed to be at least `length` samples long."""
+    """(start, length) of the `audio_length` s window centred on frame_idx / fps, clamped like the reference
+    (dataset.py:439-451): `sample = aud_sample[start : start + length]`.
+    A clip SHORTER than the window (`num_samples < length`, dataset.py:441-446): the reference zero-pads the array to
+    `length` samples but keeps clamping with the UN-updated `max_len`, so start = num_samples - length is NEGATIVE and the
+    slice of the padded array runs from index `num_samples` to index `num_samples` -- an empty sample (which its librosa
+    call then rejects).  The same (start, length) come back here; `trim_audio` applies them exactly as the reference does."""
     length = int(audio_length * sampling_rate)
     start_sec = float(frame_idx / vid_fps) - (audio_length / 2)
     start = int(max(0, start_sec * sampling_rate))
     if start + length > num_samples:
         start = num_samples - length
     return start, length
+
+
+def trim_audio(aud_sample, frame_idx, audio_length, sampling_rate=24000, vid_fps=60):
+    """reference `_get_audio_segment` (core/dataset/dataset.py:439-451) on a 1-D waveform -- NumPy array or torch tensor,
+    host or device (a view, no copy, unless the clip must be padded): the `audio_length`-second window centred on
+    frame_idx / fps, clamped to the clip.  A clip shorter than the window is zero-padded at its end (:441-442) and then
+    sliced with the reference's own un-updated `max_len` (:447-450) -- Python's negative-start slice of the padded array,
+    which is EMPTY; `Spectrogram` refuses an empty sample like the reference's librosa call does.  Nothing is "fixed"."""
+    start, length = trim_audio_window(int(aud_sample.shape[0]), frame_idx, audio_length, sampling_rate, vid_fps)
+    if aud_sample.shape[0] < length:
+        pad = length - int(aud_sample.shape[0])
+        if torch.is_tensor(aud_sample):
+            aud_sample = torch.nn.functional.pad(aud_sample, (0, pad))
+        else:
+            aud_sample = np.pad(aud_sample, (0, pad))
+    return aud_sample[start:start + length]
 
 
 def _hz_to_mel(f):
@@ -73,6 +93,8 @@ class Spectrogram:
             raise TbnHipError("Spectrogram: the STFT kernel needs the waveform on the GPU (no CPU fallback)")
         wave = wave.contiguous().float()
         nseg, L = wave.shape
+        if L < 1:       # librosa 0.7.2 (reference dataset.py:487-495) rejects it too: "Input is too short" (util.frame)
+            raise ValueError("Spectrogram: empty audio sample (a clip shorter than audio_length, reference dataset.py:441-451)")
         W = 1 + (L - 1) // 120
         spec = torch.empty(nseg, 256, W, device=wave.device, dtype=torch.float32)
         eps = float(self.eps) if self.spec_type == "stft" else 0.0

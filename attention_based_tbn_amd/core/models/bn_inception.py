@@ -20,7 +20,7 @@ import torch
 import torch.nn as nn
 
 from ... import _lib
-from ..._lib import BackboneGrads, BackboneParams, ConvInfo, TbnHipError, call, lib, ptr, stream_ptr
+from ..._lib import BUCKET_CB, BackboneGrads, BackboneParams, ConvInfo, TbnHipError, call, lib, ptr, stream_ptr
 from ... import ops
 
 # block table: name, has_1x1, has_pool_proj   (layer hyper-parameters come from the engine)
@@ -54,6 +54,7 @@ class _Plan:
         self.out_shape = (frames, oh.value, ow.value, oc.value)
         self.pool = []  # [tensor, weakref-to-token or None]
         self.tuned = {True: False, False: False}   # per mode (training / eval)
+        self.synced = {True: False, False: False}  # data parallel: this mode's choices are rank 0's (PlanSync)
 
     def workspace(self, training, device, token=None):
         need = lib().tbn_backbone_workspace_bytes(self.handle, int(training))
@@ -75,6 +76,18 @@ class _Plan:
 
     def import_choices(self, blob):
         call("tbn_backbone_plan_import", self.handle, C.c_char_p(bytes(blob)), len(blob))
+
+    def clear_pairs(self):
+        """drops every sibling-pair decision of the tuned plan (per GEMM 26 ints after the 8-int header: [4] eval forward,
+        [12] training forward, [20] data gradient hold the pair flags): each 3x3 | double_3x3_1 pair then runs as its two
+        tuned single launches.  Used where two programs must launch the SAME kernels to be compared bit for bit
+        (tests/test_branch_gpu.py: the branch-mode program never pairs)"""
+        import struct
+        blob = bytearray(self.export_choices())
+        for g in range((len(blob) - 32) // 104):
+            for k in (4, 12, 20):
+                struct.pack_into("<i", blob, 32 + 104 * g + 4 * k, 0)
+        self.import_choices(bytes(blob))
 
     def fingerprint(self):
         return "%016x" % lib().tbn_backbone_plan_fingerprint(self.handle)
@@ -151,17 +164,23 @@ class _BackboneFn(torch.autograd.Function):
                              ptr(module.running_var), 0.1, 1e-5, module._side_stream_ptr(), module._engine_flags())
         feat_ptr = C.c_void_p()
         st = stream_ptr()
-        if module.autotune and not plan.tuned[training]:
+        sync = module.plan_sync
+        if module.autotune and (not plan.tuned[training] or (sync is not None and not plan.synced[training])):
             # first use of this (shape, mode): run once so every buffer holds real data, time the tile
             # candidates of each layer on it, then do the real forward below with the tuned plan.
             # Data parallel (`plan_sync` set by core.models.DataParallel): only rank 0 tunes; its choices travel to
             # every replica (tbn_backbone_plan_export / _import), so that all ranks run the SAME kernels -- per-rank
-            # tuning from noisy on-box timings would let replicas differ and make the job's step the slowest plan's
-            sync = module.plan_sync
-            cached = plan.load_cached(module.in_channels, training) if (sync is None or sync.is_source()) else False
+            # tuning from noisy on-box timings would let replicas differ and make the job's step the slowest plan's.
+            # The exchange is a COLLECTIVE every rank must enter for the same (problem, mode): PlanSync.check gathers the
+            # key first and raises on every rank when they differ (round-5 advisor); a rank that tuned this plan before it
+            # was wrapped still takes part (`synced`, not `tuned`, decides) and adopts rank 0's choices.
+            if sync is not None:
+                sync.check((module.in_channels,) + plan.key + (int(training),), x.device)
+            tune_here = not plan.tuned[training] and (sync is None or sync.is_source())
+            cached = plan.load_cached(module.in_channels, training) if tune_here else False
             if cached:
                 pass                     # TBN_PLAN_CACHE: choices of an earlier process (same library version, same problem)
-            elif sync is None or sync.is_source():
+            elif tune_here:
                 saved = (module.running_mean.clone(), module.running_var.clone())
                 call("tbn_backbone_forward", plan.handle, int(training), ptr(x), C.byref(prm), ptr(ws), ws.numel(),
                      C.byref(feat_ptr), st)
@@ -171,6 +190,7 @@ class _BackboneFn(torch.autograd.Function):
                 plan.store_cached(module.in_channels, training)
             if sync is not None:
                 plan.import_choices(sync.broadcast(plan.export_choices(), x.device))
+                plan.synced[training] = True
             plan.tuned[training] = True
         call("tbn_backbone_forward", plan.handle, int(training), ptr(x), C.byref(prm), ptr(ws), ws.numel(),
              C.byref(feat_ptr), st)
@@ -231,9 +251,29 @@ class _BackboneFn(torch.autograd.Function):
             if a is None:
                 a = module._aux_streams[cur.cuda_stream] = torch.cuda.Stream(device=dout.device)
             aux = a.cuda_stream
-        grads = BackboneGrads(ptr(dw), ptr(db), ptr(dg), ptr(dbe), 2 if bn_rest else (1 if bn_first else 0), aux)
+        # Gradient buckets (data parallel; include/tbn_hip.h tbn_backbone_grads.bucket_cb): the engine calls back as soon as
+        # the weight gradients of inception_5a..5b, then of 4a..4e, are enqueued; `grad_bucket_fn` (set by DataParallel)
+        # starts the all-reduce of that slice of `dw` behind this stream, so it runs under the 3x / stem layers of the pass.
+        # A handle it returns is waited for (a stream-level wait under RCCL) before `dw` is handed to autograd.
+        bucket_fn = module.grad_bucket_fn if need[1] else None
+        waits, failure = [], []
+
+        def on_bucket(_user, first, count):
+            try:                                   # an exception must not unwind through the C frames of the engine
+                w = bucket_fn(module.flat_weight, dw, int(first), int(first) + int(count))
+                if w is not None:
+                    waits.append(w)
+            except BaseException as e:             # noqa: B902 -- re-raised below, after the engine call has returned
+                failure.append(e)
+
+        cb = BUCKET_CB(on_bucket) if bucket_fn is not None else BUCKET_CB()
+        grads = BackboneGrads(ptr(dw), ptr(db), ptr(dg), ptr(dbe), 2 if bn_rest else (1 if bn_first else 0), aux, cb, 0)
         call("tbn_backbone_backward", plan.handle, ptr(dfeat), C.byref(prm), C.byref(grads), ptr(ws), ws.numel(), st)
         ctx.token = None  # workspace may be reused now
+        for w in waits:
+            w()
+        if failure:
+            raise failure[0]
         n0 = module.first_bn_channels
         return (None, dw if need[1] else None, db if need[2] else None,
                 dg[:n0] if need[3] else None, dg[n0:] if need[4] else None,
@@ -263,7 +303,11 @@ class BNInception(nn.Module):
         # branch mode -- and bit-identical to the stand-alone passes
         self.use_riders = True
         self._out_slot = None       # set by TBNModel for one forward: where the pooled (frames, 1024) feature is to be written
-        self.plan_sync = None       # data parallel: object with is_source() / broadcast(blob, device) (DataParallel.PlanSync)
+        self.plan_sync = None       # data parallel: object with is_source() / check(key, device) / broadcast(blob, device)
+                                    # (DataParallel.PlanSync).  A forward that only SOME ranks run (validation on rank 0)
+                                    # must set it to None first: the exchange is a collective
+        self.grad_bucket_fn = None  # data parallel: fn(param, fresh_grad, lo, hi) -> waiter or None, called from inside backward
+                                    # as slices of the flat weight gradient become final (DataParallel._on_grad_bucket)
         self._plans = OrderedDict()
         # layer table from the engine (needs the library, not a GPU)
         probe = C.c_void_p()

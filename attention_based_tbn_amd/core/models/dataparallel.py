@@ -45,6 +45,19 @@ class PlanSync:
     def is_source(self):
         return dist.get_rank(self.group) == self.src
 
+    def check(self, key, device):
+        """every rank must be about to exchange the plan of the SAME problem and mode: all-gather the key and raise on every
+        rank alike when they differ (a last batch whose frame count differs between ranks, a rank in eval while the others
+        train) -- the alternative is a broadcast that pairs a blob with the wrong plan, or ranks waiting in different
+        collectives.  What this cannot catch is a rank that never gets here (a forward run by a subset of the ranks): such
+        callers set `module.plan_sync = None` first (BNInception.plan_sync)."""
+        keys = [None] * dist.get_world_size(self.group)
+        dist.all_gather_object(keys, tuple(int(v) for v in key), group=self.group)
+        if any(k != keys[0] for k in keys):
+            raise RuntimeError("PlanSync: the ranks are exchanging engine plans for different problems "
+                               "(in_channels, frames, H, W, training) = %s; every rank must run the same shapes in the same "
+                               "mode, or bypass the exchange with plan_sync = None" % (keys,))
+
     def broadcast(self, blob, device):
         t = torch.frombuffer(bytearray(blob), dtype=torch.uint8)
         if dist.get_backend(self.group) == "nccl":
@@ -69,7 +82,9 @@ class DataParallel(nn.Module):
         self.overlap = overlap          # False: every collective at the end of backward (diagnostic)
         self.time_sync = False          # bench: bracket finish_gradient_sync with events (exposed all-reduce time)
         self._sync_events = []
-        self._pending = []              # (param, work) of the collectives issued from gradient hooks
+        self._pending = []              # (param, reduced view of its .grad, work) of the collectives issued from gradient hooks
+        self._bucketed = {}             # id(param) -> lowest element already exchanged from inside its backward (buckets)
+        self.bucket_log = []            # (parameter numel, lo, hi) of every bucket collective, in issue order (tests, bench)
         self._fired = set()             # ids of the parameters whose gradient hook ran in this backward
         self._callback_queued = False
         self._hooks = []
@@ -78,6 +93,7 @@ class DataParallel(nn.Module):
         self._side_stream = None
         self._host_flag = None
         self._forwards_pending = 0      # training forwards since the last synchronised backward (see forward())
+        self._unsynced = False          # a backward under no_sync() has left LOCAL sums in .grad since the last exchange
         self.world_size = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
         if force_sync and not (dist.is_available() and dist.is_initialized()):
             raise RuntimeError("DataParallel(force_sync=True) needs an initialised process group")
@@ -90,6 +106,9 @@ class DataParallel(nn.Module):
                 for m in self.module.modules():
                     if hasattr(m, "plan_sync"):
                         m.plan_sync = sync       # BNInception: autotune on rank 0 only, choices broadcast
+            for m in self.module.modules():
+                if hasattr(m, "grad_bucket_fn"):
+                    m.grad_bucket_fn = self._on_grad_bucket     # BNInception: slices of the flat gradient as they become final
             for p in self.module.parameters():
                 if p.requires_grad:
                     self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad_ready))
@@ -180,19 +199,62 @@ class DataParallel(nn.Module):
         wait for the end), so the collectives match up.  Small tensors are only remembered; one callback at
         the end of backward packs and reduces them and waits for everything."""
         if not self._sync:
+            self._unsynced = True        # accumulation step: what sits in .grad now differs from rank to rank
             return
-        if not self._callback_queued:
-            self._callback_queued = True
-            self._optional = self._optional_ids()
-            self._optional_all = set(self._optional)
-            self._count = self._presence_count() if self._optional else None
-            if self._count == self.world_size:
-                self._optional = set()       # every replica produced them: ordinary, hook-overlapped reduction
-            torch.autograd.Variable._execution_engine.queue_callback(self.finish_gradient_sync)
+        self._begin_backward()
         self._fired.add(id(p))
         if self.overlap and p.grad is not None and p.grad.numel() >= self.SMALL and id(p) not in self._optional:
             _, op = self._reduce_op()
-            self._pending.append((p, dist.all_reduce(p.grad, op=op, group=self.process_group, async_op=True)))
+            # buckets of this tensor that were exchanged from inside its backward are final already: only the prefix
+            # below them is left (the stem / 3a..3c weights of a backbone)
+            view = p.grad if id(p) not in self._bucketed else p.grad.view(-1)[:self._bucketed[id(p)]]
+            if view.numel():
+                self._pending.append((p, view, dist.all_reduce(view, op=op, group=self.process_group, async_op=True)))
+            else:
+                self._pending.append((p, view, None))
+
+    def _begin_backward(self):
+        """first gradient event of a synchronised backward (a hook or a bucket): fix what is optional in THIS step and
+        queue the end-of-backward callback"""
+        if self._callback_queued:
+            return
+        self._callback_queued = True
+        self._optional = self._optional_ids()
+        self._optional_all = set(self._optional)
+        self._count = self._presence_count() if self._optional else None
+        if self._count == self.world_size:
+            self._optional = set()       # every replica produced them: ordinary, hook-overlapped reduction
+        torch.autograd.Variable._execution_engine.queue_callback(self.finish_gradient_sync)
+
+    def _on_grad_bucket(self, p, fresh, lo, hi):
+        """called from INSIDE a backbone's backward (BNInception.grad_bucket_fn, engine callback
+        tbn_backbone_grads.bucket_cb) when elements [lo, hi) of the gradient `fresh` of parameter `p` are final in stream
+        order: their all-reduce starts now and runs under the rest of that backward -- the reference's nn.DataParallel
+        reduces per backward too (core/models/model_builder.py:73-75), SURVEY 8e asks for buckets "launched as backward
+        produces them".  Only while the result is going to BE the gradient (p.grad is None: nothing accumulated locally,
+        which is the same on every rank) and the parameter is reduced from hooks at all; otherwise the whole tensor takes the
+        ordinary path.  Buckets arrive top-down (hi of one = lo of the previous), on every rank alike.
+        Returns a waiter the backward calls before it hands `fresh` to autograd (stream-level under RCCL)."""
+        if not (self.active and self._sync and self.overlap) or p.grad is not None or hi - lo < self.SMALL:
+            return None
+        self._begin_backward()
+        if id(p) in self._optional:
+            return None
+        if self._bucketed.get(id(p), fresh.numel()) != hi:
+            return None                  # not the next slice down: leave the rest to the hook
+        avg, op = self._reduce_op()
+        view = fresh.view(-1)[lo:hi]
+        work = dist.all_reduce(view, op=op, group=self.process_group, async_op=True)
+        self._bucketed[id(p)] = lo
+        self.bucket_log.append((fresh.numel(), lo, hi))
+        if len(self.bucket_log) > 64:
+            del self.bucket_log[:-64]
+
+        def wait():
+            work.wait()
+            if not avg:
+                view.div_(self.world_size)
+        return wait
 
     def finish_gradient_sync(self):
         """average every gradient produced by this backward across ranks (RCCL all-reduce): one collective per
@@ -206,7 +268,12 @@ class DataParallel(nn.Module):
             ev0.record()
         optional = getattr(self, "_optional", set())
         count = getattr(self, "_count", None)
-        nobody = count == 0                  # known before backward: no replica used the optional parameters
+        # "nobody": known before backward that no replica used the optional parameters in THIS iteration -- their
+        # reduction is skipped and .grad stays as it is (None after zero_grad, or what earlier SYNCHRONISED iterations of an
+        # accumulation window left there: identical on every rank already; reference core/tools/train.py:71-94 keeps
+        # accumulating into .grad and steps on it).  Not when a no_sync() backward has left rank-local sums behind: those
+        # still have to be exchanged, whoever produced them (round-5 advisor)
+        nobody = count == 0 and not self._unsynced
         mismatch = False
         if count is not None:
             # the exchanged draw must describe THIS backward: a rank whose optional parameters fired although "nobody"
@@ -224,22 +291,25 @@ class DataParallel(nn.Module):
                 raise RuntimeError(self._MISMATCH % (count, self.world_size))
             # "nobody" was exchanged but this rank produced them: the peers' schedule (optional tensors skipped) is one
             # this rank can follow exactly -- it does, with a flag in the packed buffer, and all ranks raise together
-            mismatch = count == 0 and any(produced)
-        in_flight = {id(p) for p, _ in self._pending}
+            mismatch = nobody and any(produced)
+        in_flight = {id(p) for p, _, _ in self._pending}
         params = [p for p in self.module.parameters() if p.requires_grad]      # registration order: rank independent
         present = {}
         for p in params:
             if id(p) in optional:
-                present[id(p)] = p.grad is not None and id(p) in self._fired
+                # whatever this rank holds travels: the gradient of this backward, and / or what earlier iterations of an
+                # accumulation window accumulated (a rank that dropped the branch NOW still contributes its accumulated
+                # part -- under per-iteration synchronisation that part is the same on every rank and averages to itself)
+                present[id(p)] = p.grad is not None
                 if not present[id(p)] and not nobody:
-                    p.grad = torch.zeros_like(p)         # this rank dropped it: contributes zeros, same schedule
+                    p.grad = torch.zeros_like(p)         # nothing here: contributes zeros, same schedule
         # a non-optional parameter without a gradient is skipped -- on every rank alike (same contract as torch DDP
         # with find_unused_parameters=False); small ones still travel (as zeros) so that the packed size is fixed
         # ("nobody": the optional tensors are skipped -- also on a rank whose backward produced them against the draw)
         late_large = [p for p in params if p.numel() >= self.SMALL and id(p) not in in_flight and p.grad is not None
                       and not (nobody and id(p) in optional)]
         small = [p for p in params if p.numel() < self.SMALL]
-        works = [w for _, w in self._pending]
+        works = [w for _, _, w in self._pending if w is not None]
         works += [dist.all_reduce(p.grad, op=op, group=self.process_group, async_op=True) for p in late_large]
         opt_list = [p for p in params if id(p) in optional]
         flat = None
@@ -255,8 +325,9 @@ class DataParallel(nn.Module):
         for work in works:
             work.wait()          # stream-level wait on RCCL; host-blocking only on gloo
         if not avg:
-            for p, _ in self._pending:
-                p.grad.div_(self.world_size)
+            for _, view, w in self._pending:
+                if w is not None:
+                    view.div_(self.world_size)
             for p in late_large:
                 p.grad.div_(self.world_size)
             if flat is not None:
@@ -271,22 +342,29 @@ class DataParallel(nn.Module):
                 if count is None:
                     # the module does not report its draw: one host read per step tells which tensors nobody produced
                     anyone = (flat[off:off + len(opt_list)].cpu() > 0).tolist()
+                elif nobody:
+                    anyone = [True] * len(opt_list)            # skipped above: .grad is left exactly as it was
+                elif count == 0 or self._unsynced:
+                    # rank-local accumulated sums were exchanged; which tensors NO rank held anything for is only in the flags
+                    anyone = (flat[off:off + len(opt_list)].cpu() > 0).tolist()
                 else:
-                    anyone = [not nobody] * len(opt_list)      # exchanged after forward: no end-of-step host read
+                    anyone = [True] * len(opt_list)            # some replica produced them in this very backward
                 for p, a in zip(opt_list, anyone):
                     if not a:
-                        p.grad = None                      # no replica produced it: the optimiser skips it
+                        p.grad = None                      # no replica holds a gradient for it: the optimiser skips it
             if count is not None:
                 self._stash_peer_flag(flat[-1:])           # read at the NEXT forward / backward: no end-of-step host sync
         if ev0 is not None:
             ev1.record()
             self._sync_events.append((ev0, ev1))
         self._pending = []
+        self._bucketed = {}
         self._fired = set()
         self._callback_queued = False
         self._presence = None
         self._count = None
         self._forwards_pending = 0
+        self._unsynced = False
         if mismatch:
             # this rank followed the peers' schedule, i.e. its optional gradients were NOT reduced: drop them (the peers
             # hold None as well, so the replicas stay identical) and fail here; the peers fail at their next forward /
@@ -327,12 +405,14 @@ class DataParallel(nn.Module):
     def _drain_and_reset(self):
         """error paths: wait for every collective already issued on p.grad (an exception must not leave RCCL writing
         into gradients the caller may free or reuse), then clear the per-step state"""
-        for _, work in self._pending:
+        for _, _, work in self._pending:
             try:
-                work.wait()
+                if work is not None:
+                    work.wait()
             except Exception:      # the collective itself failed: nothing left to drain
                 pass
         self._pending, self._fired, self._callback_queued, self._presence, self._count = [], set(), False, None, None
+        self._bucketed = {}
         self._forwards_pending = 0
 
     def _abort_group(self):

@@ -24,11 +24,16 @@ iteration and `step()` on the stepping ones.
 Data parallel (`core.models.DataParallel`, one process per GPU): the reference's nn.DataParallel reduces the replicas'
 gradients into the master copy on EVERY backward, and its per-iteration clip sees that global accumulated gradient.
   * clip_grad off: accumulation is linear, so the non-stepping iterations run under `DataParallel.no_sync()` and the
-    stepping iteration's all-reduce averages the locally accumulated sums -- one gradient exchange per optimiser step;
+    stepping iteration's all-reduce averages the locally accumulated sums -- one gradient exchange per optimiser step.
+    Parameters that a replica may leave without a gradient in some iteration (the audio branch under
+    `data.audio.dropout > 0`, reference model.py:215-222) are part of that exchange with whatever each rank accumulated:
+    `DataParallel.finish_gradient_sync` sends a rank's existing .grad (zeros where it has none) and only reports "no
+    gradient" when NO rank holds one (tests/test_host_cpu.py::test_accumulation_with_optional_branch_gloo_world2);
   * clip_grad on: the clip coefficient is a function of the norm of the GLOBAL accumulated gradient, which no rank can
     form from local data, so every iteration synchronises (avg_r(G + g_r) = G + avg_r(g_r): the previously synchronised
     part G is identical on all ranks) -- identical to the reference, at the reference's own communication volume.
 """
+import collections
 import contextlib
 
 import torch
@@ -46,7 +51,8 @@ class TrainStep:
         self.k = int(accumulator_step)
         self.clip_grad = clip_grad if clip_grad else None    # reference: `if cfg.train.clip_grad:`
         self.last_total_norm = None     # 0-dim device tensor of the last clip (None when clipping is off)
-        self.synced = []                # per iteration: did this backward exchange gradients (data parallel only)
+        # did the backward of the last iterations exchange gradients (data parallel only)?  Bounded: a run has millions
+        self.synced = collections.deque(maxlen=64)
 
     @classmethod
     def from_config(cls, cfg, model, optimizer, criterion):

@@ -17,6 +17,7 @@ void tbn_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+#if TBN_EXPERIMENT
 int tbn_env_int(const char* name, int def, int lo, int hi) {
   const char* e = getenv(name);
   if (e == nullptr || *e == 0) return def;
@@ -29,6 +30,7 @@ int tbn_env_int(const char* name, int def, int lo, int hi) {
   if ((int)v != def) fprintf(stderr, "[tbn] experiment knob %s=%ld active (default %d): not the shipped configuration\n", name, v, def);
   return (int)v;
 }
+#endif
 
 #define TBN_TRY(expr)                \
   do {                               \
@@ -55,6 +57,7 @@ static void conv_geom(ConvP* p, int n, int h, int w, int cin, int cout, int k, i
 
 // ------------------------------------------------------------------ in-process conv-GEMM profiler
 #include <map>
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -147,10 +150,28 @@ struct TlRec {
   hipEvent_t a, b;
 };
 std::mutex g_tl_mu;
-bool g_tl_on = false;
+std::atomic<bool> g_tl_on{false};   // read by every launch, from every host thread that drives a backbone stream
 std::vector<TlRec> g_tl;
+void tl_free_events() {             // caller holds g_tl_mu
+  for (auto& r : g_tl) {
+    if (r.a) (void)hipEventDestroy(r.a);
+    if (r.b) (void)hipEventDestroy(r.b);
+  }
+  g_tl.clear();
+}
 }  // namespace
-bool tbn_tl_on() { return g_tl_on; }
+// A launch takes the timeline path only outside stream captures: an event-carrying dispatch inside hipStreamBeginCapture
+// invalidates the capture (TrainStep / scripts/graph_experiment.py capture whole steps) -- such launches are simply not
+// on the timeline (round-5 advisor).
+bool tbn_tl_on(hipStream_t st) {
+  if (!g_tl_on.load(std::memory_order_relaxed)) return false;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cs) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  return cs == hipStreamCaptureStatusNone;
+}
 void tbn_tl_events(const char* name, hipStream_t st, hipEvent_t* start, hipEvent_t* stop) {
   std::lock_guard<std::mutex> lk(g_tl_mu);
   TlRec r;
@@ -163,16 +184,15 @@ void tbn_tl_events(const char* name, hipStream_t st, hipEvent_t* start, hipEvent
   *stop = r.b;
   g_tl.push_back(r);
 }
+// enable(1) starts a fresh recording; enable(0) stops it and keeps the records for tbn_timeline_dump, which frees them
+// (their events included) once written -- a disabled, dumped timeline holds no events
 extern "C" int tbn_timeline_enable(int on) {
   std::lock_guard<std::mutex> lk(g_tl_mu);
   if (on) {
-    for (auto& r : g_tl) {
-      (void)hipEventDestroy(r.a);
-      (void)hipEventDestroy(r.b);
-    }
-    g_tl.clear();
+    (void)hipDeviceSynchronize();   // no launch of an earlier recording may still carry the events freed here
+    tl_free_events();
   }
-  g_tl_on = on != 0;
+  g_tl_on.store(on != 0, std::memory_order_relaxed);
   return TBN_OK;
 }
 extern "C" int tbn_timeline_dump(const char* path) {
@@ -199,6 +219,7 @@ extern "C" int tbn_timeline_dump(const char* path) {
     }
   }
   fclose(f);
+  if (!g_tl_on.load(std::memory_order_relaxed)) tl_free_events();   // device is idle (synchronised above), recording is off
   return TBN_OK;
 }
 bool tbn_prof_launch_events(hipEvent_t* start, hipEvent_t* stop) {
@@ -249,7 +270,7 @@ __global__ __launch_bounds__(256) void mfma_burst_kernel(float* sink, int iters)
 
 extern "C" {
 
-int tbn_version(void) { return 101; }
+int tbn_version(void) { return 102 | (TBN_EXPERIMENT ? 0x10000 : 0); }
 
 int tbn_diag_mfma_burst(float* sink, int workgroups, int iters, double* flops, void* stream) {
   TBN_REQUIRE(sink != nullptr && workgroups > 0 && workgroups <= 65536 && iters > 0, "diag_mfma_burst: bad argument");

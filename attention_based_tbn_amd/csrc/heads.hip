@@ -368,7 +368,9 @@ __global__ __launch_bounds__(256) void dropout_fwd_kernel(const float* __restric
 // int64 labels label[h][b].  One workgroup per (head, sample): max / sum-exp by wavefront reduction, then
 //   rowloss[h * B + b] = logsumexp - score[label],   dscores[b][c] = (softmax_c - [c == label]) / B   (columns outside every
 // head are left untouched: the caller zero-fills).  The mean over b is a fixed-order sum in ce_heads_mean_kernel
-// (deterministic); out-of-range labels poison the loss with NaN instead of reading out of bounds.
+// (deterministic).  A label of -100 is nn.CrossEntropyLoss's default ignore_index: the row gives no loss and no gradient
+// and the mean divides by the number of the other rows; any other out-of-range label poisons the loss with NaN instead of
+// reading out of bounds (torch raises a device assert there).
 struct CeHeads {
   int n;
   int col0[4], ncls[4];
@@ -377,17 +379,27 @@ struct CeHeads {
 __global__ __launch_bounds__(256) void ce_heads_fwd_kernel(const float* __restrict__ scores, int ld, CeHeads hd, int B,
                                                            float* __restrict__ rowloss, float* __restrict__ dscores) {
   __shared__ float red[8];
+  __shared__ int cnt[4];
   const int h = blockIdx.x / B, b = blockIdx.x - h * B;
   const int C = hd.ncls[h];
   const float* s = scores + (size_t)b * ld + hd.col0[h];
   float* d = dscores + (size_t)b * ld + hd.col0[h];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // nn.CrossEntropyLoss(ignore_index=-100, reduction="mean"): a row labelled -100 contributes neither loss nor gradient
+  // and the mean runs over the OTHER rows -- every workgroup counts them itself (B int64 labels: a few hundred bytes)
+  int valid = 0;
+  for (int i = tid; i < B; i += 256) valid += hd.label[h][i] != -100 ? 1 : 0;
+  for (int o = 32; o > 0; o >>= 1) valid += __shfl_xor(valid, o);
   float mx = -INFINITY;
   for (int c = tid; c < C; c += 256) mx = fmaxf(mx, s[c]);
   for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-  if (lane == 0) red[wave] = mx;
+  if (lane == 0) {
+    red[wave] = mx;
+    cnt[wave] = valid;
+  }
   __syncthreads();
   mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  valid = (cnt[0] + cnt[1]) + (cnt[2] + cnt[3]);
   float se = 0.f;
   for (int c = tid; c < C; c += 256) se += expf(s[c] - mx);
   for (int o = 32; o > 0; o >>= 1) se += __shfl_xor(se, o);
@@ -395,19 +407,28 @@ __global__ __launch_bounds__(256) void ce_heads_fwd_kernel(const float* __restri
   __syncthreads();
   se = (red[4] + red[5]) + (red[6] + red[7]);
   const long long lab = hd.label[h][b];
+  const bool ignored = lab == -100;
   const bool ok = lab >= 0 && lab < C;
-  const float lse = mx + logf(se), inv = 1.f / se, invB = 1.f / (float)B;
-  for (int c = tid; c < C; c += 256) d[c] = (expf(s[c] - mx) * inv - ((long long)c == lab ? 1.f : 0.f)) * invB;
-  if (tid == 0) rowloss[h * B + b] = ok ? lse - s[lab] : NAN;
+  const float lse = mx + logf(se), inv = 1.f / se, invB = ignored ? 0.f : 1.f / (float)valid;
+  for (int c = tid; c < C; c += 256)
+    d[c] = ignored ? 0.f : (expf(s[c] - mx) * inv - ((long long)c == lab ? 1.f : 0.f)) * invB;
+  if (tid == 0) rowloss[h * B + b] = ignored ? 0.f : (ok ? lse - s[lab] : NAN);   // any other out-of-range label: NaN
 }
-__global__ __launch_bounds__(64) void ce_heads_mean_kernel(const float* __restrict__ rowloss, int B, int nheads,
+__global__ __launch_bounds__(64) void ce_heads_mean_kernel(const float* __restrict__ rowloss, CeHeads hd, int B, int nheads,
                                                            float* __restrict__ loss) {
   const int h = blockIdx.x;
   if (h >= nheads) return;
   double acc = 0.0;
-  for (int b = threadIdx.x; b < B; b += 64) acc += (double)rowloss[h * B + b];
-  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-  if (threadIdx.x == 0) loss[h] = (float)(acc / (double)B);
+  int valid = 0;
+  for (int b = threadIdx.x; b < B; b += 64) {
+    acc += (double)rowloss[h * B + b];
+    valid += hd.label[h][b] != -100 ? 1 : 0;
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    acc += __shfl_xor(acc, o);
+    valid += __shfl_xor(valid, o);
+  }
+  if (threadIdx.x == 0) loss[h] = (float)(acc / (double)valid);   // no valid row: 0 / 0 = NaN, as torch
 }
 // dscores *= per-head upstream gradient (d total / d loss_h): the backward of the fused cross entropy
 __global__ __launch_bounds__(256) void ce_heads_bwd_kernel(const float* __restrict__ dsc, int ld, CeHeads hd, int B,
@@ -444,7 +465,7 @@ int tbn_ce_heads_fwd(const float* scores, int ld, int batch, int num_heads, cons
   TBN_KLAUNCH(ce_heads_fwd_kernel, dim3(num_heads * batch), dim3(256), 0, (hipStream_t)stream, scores, ld, hd, batch, rowloss,
               dscores);
   TBN_CHECK_LAUNCH("ce_heads_fwd");
-  TBN_KLAUNCH(ce_heads_mean_kernel, dim3(num_heads), dim3(64), 0, (hipStream_t)stream, rowloss, batch, num_heads, loss);
+  TBN_KLAUNCH(ce_heads_mean_kernel, dim3(num_heads), dim3(64), 0, (hipStream_t)stream, rowloss, hd, batch, num_heads, loss);
   TBN_CHECK_LAUNCH("ce_heads_mean");
   return TBN_OK;
 }

@@ -397,7 +397,8 @@ class _CeHeadsFn(torch.autograd.Function):
 
 def cross_entropy_heads(scores, heads, labels):
     """scores (B, ld) contiguous; heads = [(first column, classes)]; labels = [int64 (B,)] -> tuple of 0-dim losses
-    (nn.CrossEntropyLoss() with its defaults, per head).  Labels outside [0, classes) give NaN, not an error."""
+    (nn.CrossEntropyLoss() with its defaults, per head: a label of -100 is ignored -- no loss, no gradient, the mean runs
+    over the other rows).  Any other label outside [0, classes) gives NaN, not an error."""
     return _CeHeadsFn.apply(scores, tuple(heads), *labels)
 
 

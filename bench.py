@@ -127,7 +127,7 @@ def _median(v):
     return v[len(v) // 2] if len(v) % 2 else 0.5 * (v[len(v) // 2 - 1] + v[len(v) // 2])
 
 
-def roofline_object(samples, steps_in_first_sample, end_to_end_frac):
+def roofline_object(samples, steps_in_first_sample, end_to_end_frac, sched=None):
     """`roofline` of the JSON line from the per-step profiler collections (instrumented single-stream steps run after the
     timed loop): the dominant kernel = the conv-GEMM instantiation with the largest summed time; `achieved` / `frac` and
     the conv-stage figure `all_conv_gemm` are MEDIANS over the samples, min / max beside them."""
@@ -162,8 +162,20 @@ def roofline_object(samples, steps_in_first_sample, end_to_end_frac):
         fam[f_] = fam.get(f_, 0) + e["launches"] // (steps_in_first_sample if len(conv) == 1 else 1)
     P = PEAK_FP32_MFMA_TFLOPS
     nstep_total = steps_in_first_sample if len(conv) == 1 else len(conv)     # profiled steps behind the totals
-    return {"bound": "mfma", "achieved": round(ach, 2), "peak": P, "unit": "TFLOP/s", "frac": round(ach / P, 4),
-            "frac_min": round(min(top_tf) / P, 4), "frac_max": round(max(top_tf) / P, 4), "samples": len(conv),
+    # What the line LEADS with (round-5 verdict item 4): the conv stage as the TIMED schedule runs it -- conv FLOPs / time with
+    # at least one conv GEMM running, all modality streams, from the library's own timeline -- not one kernel in isolation.
+    # The dominant kernel's own figure (algorithmic FLOPs per launch / its average launch duration, HIP events on its
+    # dispatch packet; the rocprofv3 summary under profiles/ agrees) sits under `dominant`, the one-stream conv stage under
+    # `all_conv_gemm`.  Without timeline steps (--timeline-steps 0) the line leads with the one-stream conv stage.
+    lead = sched if sched is not None else {"achieved": round(_median(all_tf), 2), "frac": round(_median(all_tf) / P, 4)}
+    return {"bound": "mfma", "achieved": lead["achieved"], "peak": P, "unit": "TFLOP/s", "frac": lead["frac"],
+            "frac_is": "conv_stage_timed_schedule" if sched is not None else "all_conv_gemm (one stream at a time)",
+            "conv_stage_timed_schedule": sched,
+            "dominant": {"kernel": top["kernel"], "achieved": round(ach, 2), "frac": round(ach / P, 4),
+                         "frac_min": round(min(top_tf) / P, 4), "frac_max": round(max(top_tf) / P, 4),
+                         "avg_launch_us": round(_median(top_us), 2), "launches": top["launches"] // nstep_total,
+                         "alg_gflop_per_launch": round(top["flops"] / top["launches"] / 1e9, 4)},
+            "samples": len(conv),
             "sampled": "instrumented single-stream steps AFTER the timed loop, one sample per step"
                        if steps_in_first_sample == 1 or len(conv) > 1 else
                        f"{steps_in_first_sample} instrumented steps INSIDE the timed loop (--profile-every), aggregated",
@@ -373,6 +385,83 @@ def cpu_baseline():
             "other": legs}
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher's environment: start the N ranks as a CHILD process
+    (`python -m torch.distributed.run --nproc-per-node N bench.py <same arguments>`, rendezvous on 127.0.0.1), relay its
+    stdout -- exactly one JSON line, from rank 0 -- and return its exit code.  This parent never touches the GPU (no
+    torch.cuda call, no rocm-smi): the pool refuses an exec from a process that has, and a child is what it asks for."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL / tensor sharing across the rank processes
+    env.setdefault("OMP_NUM_THREADS", "4")
+    print("[bench] no RANK / WORLD_SIZE in the environment: launching %d ranks: %s" % (n, " ".join(cmd)), file=sys.stderr)
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    sys.stdout.write(r.stdout)
+    sys.stdout.flush()
+    return r.returncode
+
+
+def timed_schedule_conv_stage(step, nsteps, conv_flops_per_step):
+    """the conv stage AS THE TIMED SCHEDULE RUNS IT: `nsteps` more product steps (all streams, nothing serialised) under the
+    library's own kernel timeline (tbn_timeline_enable: begin / end of every launch on its dispatch packet, ~2 % on the
+    step, the modality streams keep overlapping -- an external tracer serialises them, profiles/HISTORY.md finding 17);
+    achieved = conv FLOPs of those steps / the time during which at least one conv GEMM was running."""
+    import csv
+    import tempfile
+    from attention_based_tbn_amd._lib import lib
+    L = lib()
+    torch.cuda.synchronize()
+    L.tbn_timeline_enable(1)
+    for _ in range(nsteps):
+        step()
+    torch.cuda.synchronize()
+    L.tbn_timeline_enable(0)
+    fd, path = tempfile.mkstemp(suffix=".csv", prefix="tbn_timeline_")
+    os.close(fd)
+    try:
+        if L.tbn_timeline_dump(path.encode()) != 0:
+            return None
+        iv, first, last, n_all = [], None, None, 0
+        with open(path) as f:
+            for r in csv.DictReader(f):
+                a, b = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+                n_all += 1
+                first = a if first is None else min(first, a)
+                last = b if last is None else max(last, b)
+                nm = r["Kernel_Name"]
+                if any(k in nm for k in ("conv_wgrad", "conv_igemm", "conv_halo", "conv_dma", "conv_pair", "conv_sk4")):
+                    iv.append((a, b))
+    finally:
+        os.unlink(path)
+    if not iv:
+        return None
+    iv.sort()
+    union, summed, cur_a, cur_b = 0, 0, iv[0][0], iv[0][1]
+    for a, b in iv:
+        summed += b - a
+        if a > cur_b:
+            union += cur_b - cur_a
+            cur_a, cur_b = a, b
+        else:
+            cur_b = max(cur_b, b)
+    union += cur_b - cur_a
+    tf = nsteps * conv_flops_per_step / (union * 1e-9) / 1e12
+    return {"achieved": round(tf, 2), "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4), "steps": nsteps,
+            "gemm_running_ms_per_step": round(union / nsteps / 1e6, 3),
+            "gemm_kernel_ms_per_step": round(summed / nsteps / 1e6, 3),
+            "gemms_in_flight_while_running": round(summed / union, 2),
+            "wall_ms_per_step": round((last - first) / nsteps / 1e6, 3), "launches_per_step": n_all // nsteps,
+            "conv_gflop_per_step": round(conv_flops_per_step / 1e9, 1),
+            "what": "conv FLOPs / time with >= 1 conv GEMM running, product steps (all modality streams) after the timed loop "
+                    "under the library's kernel timeline (tbn_timeline_enable; costs the step ~2 %)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -419,7 +508,17 @@ def main():
                     help="diagnostic: after the timed loop run 3 more steps with HIP events around every backbone "
                          "forward / backward call and print (stderr) when each ran on the GPU and how long the host took "
                          "to issue it -- the stagger between the modality streams")
+    ap.add_argument("--timeline-steps", type=int, default=4,
+                    help="product steps run AFTER the timed loop under the library's kernel timeline: `roofline.frac` is the "
+                         "conv stage of that schedule (0: skip; the line then leads with the one-stream conv stage)")
+    ap.add_argument("--high-prio", default=None,
+                    help="A/B: comma-separated modalities whose backbone stream gets the high HIP priority, or 'none' "
+                         "(default: the model's, Audio)")
+    ap.add_argument("--share-stream", default=None,
+                    help="A/B: 'Flow:RGB,...' -- a modality's backbone runs on another modality's stream (default: none)")
     args = ap.parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))      # the driver's 1-GPU command is plain `python bench.py`: N > 1 must work the same way
     # stdout carries exactly ONE line (the JSON result, rank 0): everything the model code prints while it builds
     # (the reference's "Freezing the batchnorms ..." notices, on every rank) goes to stderr
     # -- C libraries included (RCCL / gloo log to file descriptor 1): fd 1 is pointed at stderr for the run and the
@@ -447,7 +546,8 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    assert world == args.gpus, (f"--gpus {args.gpus} but the launcher's WORLD_SIZE is {world}: under torch.distributed.run pass "
+                                f"--nproc-per-node {args.gpus}, or run plain `python bench.py --gpus {args.gpus}` (it starts the ranks itself)")
 
     from attention_based_tbn_amd.config import load_config, get_modality
     from attention_based_tbn_amd.core.models import build_model
@@ -537,6 +637,10 @@ def main():
         model.time_sync = True     # HIP events around finish_gradient_sync: the all-reduce tail backward did not hide
     multi = not args.no_multi_stream
     core.multi_stream = multi
+    if args.high_prio is not None:
+        core.high_priority_modalities = tuple(x for x in args.high_prio.split(",") if x and x != "none")
+    if args.share_stream:
+        core.shared_streams = dict(item.split(":") for item in args.share_stream.split(","))
     aux = [b_.use_aux_stream and not args.no_aux_stream for b_ in bases]   # the model's own policy unless switched off
     if args.aux_streams is not None:
         aux = [m in args.aux_streams.split(",") for m in modality]
@@ -651,6 +755,11 @@ def main():
         prof_samples.append(collect_profile() if rank == 0 else [])
     if world > 1:
         fence()
+    sched = None
+    if args.timeline_steps > 0:
+        sched = timed_schedule_conv_stage(step, args.timeline_steps, B * flop_per_clip)
+        if world > 1:
+            fence()
     plan_fps = {m: "+".join(sorted(b_.plan_fingerprints().values())) for m, b_ in zip(modality, bases)}
     plans_equal = None
     if world > 1:
@@ -696,7 +805,7 @@ def main():
         clips = B * world * args.steps
         value = clips / dt
         roofline = roofline_object(prof_samples, max(1, len(range(0, args.steps, args.profile_every))) if args.profile_every > 0 else 1,
-                                   value / world * flop_per_clip / 1e12 / PEAK_FP32_MFMA_TFLOPS)
+                                   value / world * flop_per_clip / 1e12 / PEAK_FP32_MFMA_TFLOPS, sched)
         line = {
             "metric": "clips/sec (3-seg RGB+Flow+Audio TBN fwd+bwd)" if args.config == 4 and not args.forward_only
             else f"clips/sec (config {args.config}{', forward only' if args.forward_only else ''})",

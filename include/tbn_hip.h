@@ -27,6 +27,8 @@ extern "C" {
 #define TBN_ERR_LAUNCH (-2)
 #define TBN_ERR_UNSUPPORTED (-3)
 
+/* library version in the low 16 bits; bit 16 (0x10000) is set by a -DTBN_EXPERIMENT=1 build, the only build that reads
+ * A/B environment knobs (the shipped library reads no environment variable at all) */
 int tbn_version(void);
 const char* tbn_last_error(void);
 
@@ -109,6 +111,18 @@ typedef struct {
                                  fork from the capture's ORIGIN stream captures fine, but HIP offers no query that tells an
                                  origin stream from a forked one, so the guard refuses that case too -- broader than the
                                  fault, by necessity.  The Python host passes NULL while capturing (serial launches). */
+  void (*bucket_cb)(void* user, size_t first_float, size_t num_floats);
+                              /* optional (NULL: none).  Gradient buckets for data parallelism (reference: the per-backward
+                                 reduce_add_coalesced of nn.DataParallel, core/models/model_builder.py:73-75): called on the
+                                 CALLING thread, twice per backward pass, as soon as every launch that writes
+                                 dweight[first_float, first_float + num_floats) has been enqueued -- first the weights of
+                                 inception_5a..5b, then those of inception_4a..4e (a suffix of the flat tensor each time;
+                                 plan order = memory order).  Work the callback enqueues behind the launch stream (an
+                                 RCCL all-reduce of that slice) then overlaps the rest of the pass; the remaining prefix
+                                 (stem, 3a..3c) is final when the function returns.  The split depends on the graph
+                                 only: identical on every replica.  With aux_stream the launch stream is first made to
+                                 wait for the weight gradients issued so far.  Not called inside a stream capture. */
+  void* bucket_user;
 } tbn_backbone_grads;
 
 /* TBN_ERR_UNSUPPORTED for input sizes on which the reference graph itself is inconsistent (its torch.cat of the stride-2
@@ -338,8 +352,9 @@ int tbn_segment_mean_bwd(const float* dout, float* dx, int b, int n, int c, void
 int tbn_dropout_fwd(const float* x, const float* rnd, float p, float* y, float* mask, size_t count, void* stream);
 /* The cross-entropy losses of up to 4 classification heads that share ONE score matrix (reference model.py:272-279: one
  * nn.CrossEntropyLoss(mean) per class key, `verb` and `noun`): head h owns columns [col0[h], col0[h] + ncls[h]) of
- * scores (batch, ld), labels[h] = int64[batch] device pointers (host array of them).  Writes loss[h] (device, mean over
- * the batch, fixed summation order), rowloss (scratch, num_heads * batch floats) and dscores (batch, ld) =
+ * scores (batch, ld), labels[h] = int64[batch] device pointers (host array of them).  A label of -100 (the criterion's
+ * default ignore_index) takes its row out of loss, gradient and mean; any other label outside [0, ncls[h]) gives NaN.
+ * Writes loss[h] (device, mean over the rows not ignored, fixed summation order), rowloss (scratch, num_heads * batch floats) and dscores (batch, ld) =
  * d(sum_h loss[h]) / d(scores) for the heads' columns (other columns untouched).  tbn_ce_heads_bwd scales a head's columns
  * of dscores by upstream[h] (device) into `out` (may alias dscores): the backward for arbitrary per-head weights. */
 int tbn_ce_heads_fwd(const float* scores, int ld, int batch, int num_heads, const int* col0, const int* ncls,

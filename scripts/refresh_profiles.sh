@@ -64,7 +64,7 @@ python3 $ROOT/scripts/pmc_traffic.py /tmp/pmch_FETCH_SIZE/t_counter_collection.c
 for m in "rgb 3 224 224" "flow 10 224 224" "audio 1 256 256"; do
   set -- $m
   rm -rf /tmp/pmcsq_$1
-  timeout -k 10 500 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE SQ_INSTS_MFMA SQ_INSTS_VALU -d /tmp/pmcsq_$1 -o t --output-format csv -- python3 $ROOT/scripts/layer_profile.py $2 $3 $4 96 > /dev/null 2>&1
+  timeout -k 10 500 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE SQ_INSTS_MFMA SQ_INSTS_VALU -d /tmp/pmcsq_$1 -o t --output-format csv -- python3 $ROOT/scripts/layer_profile.py $2 $3 $4 96 burst > /dev/null 2>&1
   python3 $ROOT/scripts/pmc_sq.py /tmp/pmcsq_$1/t_counter_collection.csv 40 > $ROOT/$O/${TAG}_pmc_sq_$1.txt
 done
 cd $ROOT

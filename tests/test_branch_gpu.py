@@ -1,9 +1,11 @@
 """GPU: branch mode of the backbone engine (tbn_backbone_params.side_stream): the 3x3 / pool_proj chain of every
 inception block on a side stream beside the 1x1 -> double_3x3 chain.  The branches only meet at the concat (reference
 core/models/bn_inception_audio.py:437-1003, torch.cat :485-493), so the two-stream program must reproduce the serial
-one BIT FOR BIT once both launch the same kernels -- the child process runs with TBN_USE_PAIRS=0 so that the serial
-program does not merge 3x3 | double_3x3_1 into sibling-pair launches (other tiles, other partial-sum order): what is
-left to differ is only what a race between the two chains would break (shared scratch slots, a missing join)."""
+one BIT FOR BIT once both launch the same kernels -- after tuning, the sibling-pair decisions are taken out of the plan
+(`_Plan.clear_pairs`: an edit of the exported plan blob, tbn_backbone_plan_export / _import) so that the serial program
+does not merge 3x3 | double_3x3_1 into one launch (other tiles, other partial-sum order): what is left to differ is only
+what a race between the two chains would break (shared scratch slots, a missing join).  (Rounds 4-5 used the A/B knob
+TBN_USE_PAIRS=0 for this; the shipped library reads no environment variable any more.)"""
 import os
 import subprocess
 import sys
@@ -44,8 +46,10 @@ for cin, N, H, W in ((3, 6, 224, 224), (1, 5, 128, 256), (10, 3, 96, 96)):
         with torch.no_grad():
             return net(x).clone()
 
-    ref = train_step(False, False)                     # serial program, one stream (autotunes on first use)
+    train_step(False, False)                           # serial program, one stream: autotunes on first use ...
     plan = net._plans[(N, H, W)]
+    plan.clear_pairs()                                 # ... then every pair runs as its two tuned single launches
+    ref = train_step(False, False)
     assert lib().tbn_backbone_num_streams(plan.handle) == 2
     assert float(ref[1].abs().max()) > 0 and all(torch.isfinite(t).all() for t in ref)
     for rep in range(3):                               # repeated: a race need not show on the first try
@@ -53,6 +57,8 @@ for cin, N, H, W in ((3, 6, 224, 224), (1, 5, 128, 256), (10, 3, 96, 96)):
             got = train_step(branch, aux)
             for i, (a, b) in enumerate(zip(got, ref)):
                 assert torch.equal(a, b), (cin, rep, branch, aux, i, float((a - b).abs().max()))
+    eval_fwd(False)                                    # eval-mode tuning
+    plan.clear_pairs()
     e0 = eval_fwd(False)
     for rep in range(3):
         assert torch.equal(eval_fwd(True), e0), (cin, "eval", rep)
@@ -64,6 +70,6 @@ print("BRANCH_OK")
 def test_branch_mode_is_bit_identical_to_the_serial_program(tmp_path):
     script = tmp_path / "branch_worker.py"
     script.write_text(_WORKER)
-    env = dict(os.environ, TBN_USE_PAIRS="0")
+    env = dict(os.environ)
     r = subprocess.run([sys.executable, str(script), ROOT], env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "BRANCH_OK" in r.stdout, (r.stdout[-1500:] + "\n----\n" + r.stderr[-3000:])

@@ -16,7 +16,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from tests.util import build_oracle, rel_err  # noqa: E402
+from tests.util import assert_close, build_oracle, rel_err  # noqa: E402
 from tests.test_model_gpu import (DEV, PER_LAYER_COS, PER_LAYER_L2, build_product, cosine, l2_err,  # noqa: E402
                                   per_layer_grad_parity, reference_named_grads, to_dev)
 
@@ -101,8 +101,7 @@ def test_config3_full_batch_train_step_vs_oracle(audio_length, audio_w, T):
     assert bs == obs and set(out) == set(oout) and "weights" in oout
     assert tuple(out["weights"].shape) == tuple(oout["weights"].shape) == (B * n, 1, T)
     for k in oout:                                   # verb / noun logits and the attention weights
-        e = rel_err(out[k].detach().cpu(), oout[k].detach())
-        assert e < 1e-3, (k, e)
+        assert_close(out[k], oout[k], k)             # norm bound 1e-3 AND element-wise (tests/util.py)
     assert set(loss) == set(oloss) and "entropy" in oloss
     for k, v in oloss.items():
         want = float(torch.as_tensor(v).detach())
@@ -194,6 +193,5 @@ def test_config5_eval_chunks_vs_oracle():
     assert tuple(want["weights"].shape) == (B * n, 1, 8)
     for tag, out in (("eval_chunk 256", out256), ("eval_chunk 128", out128)):
         for k in want:
-            e = rel_err(out[k].cpu(), want[k])
+            e = assert_close(out[k], want[k], (tag, k))
             print("config-5 parity (%s): %s relative error %.2e" % (tag, k, e))
-            assert e < 1e-3, (tag, k, e)

@@ -43,3 +43,18 @@ def rel_err(a, b):
     a = torch.as_tensor(a).detach().double()
     b = torch.as_tensor(b).detach().double()
     return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def assert_close(got, want, what="", rtol=1e-3, atol_frac=1e-5):
+    """the north star's "within 1e-3 relative fp32 tolerance", asserted BOTH ways (round-5 verdict): the norm bound
+    max|got - want| / max|want| < rtol (`rel_err`) and element-wise |got - want| <= rtol * |want| + atol_frac * max|want|
+    (torch.allclose with an absolute floor scaled to the tensor: an element near zero may be off by 1e-5 of the largest)."""
+    a = torch.as_tensor(got).detach().double().cpu()
+    b = torch.as_tensor(want).detach().double().cpu()
+    assert a.shape == b.shape, (what, tuple(a.shape), tuple(b.shape))
+    e = rel_err(a, b)
+    assert e < rtol, (what, "norm bound", e)
+    atol = atol_frac * float(b.abs().max())
+    bad = (a - b).abs() > rtol * b.abs() + atol
+    assert not bool(bad.any()), (what, "element-wise", int(bad.sum()), float(((a - b).abs() - rtol * b.abs()).max()), atol)
+    return e
