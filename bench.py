@@ -633,6 +633,7 @@ def main():
         opt.step(clip_grad=cfg.train.clip_grad, grads_consumed=True)   # clip_grad_norm_(20) + SGD(momentum) in three HIP launches (zero_grad precedes every backward)
         return loss["total"].detach()      # no reference to the autograd graph survives the step
 
+    buckets_last_step = None
     if world > 1 and hasattr(model, "time_sync"):
         model.time_sync = True     # HIP events around finish_gradient_sync: the all-reduce tail backward did not hide
     multi = not args.no_multi_stream
@@ -735,6 +736,11 @@ def main():
     marks[args.steps].record()
     fence()
     dt = time.perf_counter() - t0
+    if world > 1 and hasattr(model, "bucket_log"):
+        model.bucket_log.clear()
+        step()                                  # one more (untimed) step: how many bucket collectives a step issues
+        torch.cuda.synchronize()
+        buckets_last_step = len(model.bucket_log)
     step_gpu_each = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
     step_gpu_ms = sorted(step_gpu_each)
     exposed_ms = None
@@ -831,6 +837,9 @@ def main():
         }
         if world > 1:
             line["multi_gpu"] = {"dist_world_size": dist.get_world_size(), "cuda_device_count": torch.cuda.device_count(),
+                                 # collectives issued from INSIDE the backbones' backward passes in the last step (two per
+                                 # backbone: inception_5a..5b, then 4a..4e; the prefix follows from the gradient hook)
+                                 "gradient_buckets_per_step": buckets_last_step,
                                  "ms_per_step_rank_min": round(min(rank_ms), 3), "ms_per_step_rank_max": round(max(rank_ms), 3),
                                  "allreduce_probe": probe}
         if exposed_ms is not None:

@@ -1,4 +1,7 @@
-"""Experiment: capture the whole config-4 train step (fwd + loss + bwd + clip + SGD) in one HIP graph and replay it."""
+"""Experiment: capture the whole train step (fwd + loss + bwd + clip + SGD) of BASELINE config CFG (default 4; CFG=2: the lone
+RGB backbone) in one HIP graph and replay it.  MULTI=0/1 modality streams, AUX=0/1 weight-gradient stream (not capturable
+together with MULTI: nested forks, profiles/HISTORY.md), BRANCH=0/1 branch-level side stream of the eager run (a captured
+step always runs the one-chain program with riders: core/models/bn_inception.py passes no side / aux stream while capturing)."""
 import faulthandler, os, sys, time, torch
 faulthandler.enable(all_threads=True)      # a SIGSEGV prints the Python stack of every thread (autograd thread included)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -8,18 +11,20 @@ from attention_based_tbn_amd.core.models import build_model
 from attention_based_tbn_amd.core.utils import FusedSGD
 
 dev = torch.device("cuda", 0)
-C_ = bench.CONFIGS[4]
+C_ = bench.CONFIGS[int(os.environ.get("CFG", "4"))]
 cfg = load_config(C_["ov"]); modality = get_modality(cfg)
 torch.manual_seed(0)
 model, criterion, _ = build_model(cfg, modality, dev); model.train()
 params = [p for p in model.parameters() if p.requires_grad]
 opt = FusedSGD(params, lr=cfg.train.optim.lr, momentum=cfg.train.optim.momentum, weight_decay=cfg.train.optim.weight_decay)
-B, n = 32, 3
+B, n = C_["batch"], 3
 inp, tgt = bench.synthetic_batch(B, n, dev, 0, modality)
 core = getattr(model, "module", model)
 core.multi_stream = os.environ.get("MULTI", "1") == "1"
 for m in modality:
     getattr(core, "Base_" + m).use_aux_stream = os.environ.get("AUX", "1") == "1"
+    if "BRANCH" in os.environ:
+        getattr(core, "Base_" + m).use_branch_streams = os.environ["BRANCH"] == "1"
 print("multi_stream", core.multi_stream, "aux", os.environ.get("AUX", "1"), flush=True)
 
 def step():

@@ -18,4 +18,12 @@ case $MODE in
       TBN_LIB=$EXP TBN_TUNE_CORUN=2 $B 2>/dev/null | line "tuned as 3 concurrent copies"
       TBN_LIB=$EXP TBN_TUNE_CORUN=2 TBN_TUNE_MIN_TILE=2 $B 2>/dev/null | line "both"
     done ;;
+  graph2)
+    ms() { grep -o '"ms_per_step": [0-9.]*'; }
+    for rep in $(seq $REPS); do
+      echo "config 2 shipped policy (branch + weight-gradient streams), eager   $(python bench.py --config 2 --steps 60 --warmup 5 --no-cpu-baseline --profile-steps 0 --timeline-steps 0 2>/dev/null | ms)"
+      echo "config 2 one chain + riders, one stream: $(CFG=2 MULTI=0 AUX=0 BRANCH=0 python scripts/graph_experiment.py 2>/dev/null | grep -E 'eager|graph replay' | tr '\n' ' ')"
+    done ;;
+  red)
+    python scripts/red_epilogue_cost.py 96 ;;
 esac

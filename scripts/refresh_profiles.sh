@@ -30,14 +30,20 @@ timeout -k 10 120 python scripts/layer_profile.py 3 224 224 96 > $O/${TAG}_layer
 timeout -k 10 120 python scripts/layer_profile.py 10 224 224 96 > $O/${TAG}_layer_profile_flow_R96_single_stream.txt 2> /dev/null
 timeout -k 10 120 python scripts/layer_profile.py 1 256 256 96 > $O/${TAG}_layer_profile_audio_R96_single_stream.txt 2> /dev/null
 timeout -k 10 120 python scripts/stft_profile.py > $O/${TAG}_stft_profile.txt 2> /dev/null
+# the un-traced multi-stream step on the library's own kernel timeline: critical-path attribution (config 4 and the lone backbone)
+for c in 4 2; do
+  timeout -k 10 300 python bench.py --config $c --steps 20 --warmup 5 --no-cpu-baseline --profile-steps 0 --timeline-steps 0 --timeline /tmp/tl_$c.csv > /dev/null 2>&1
+  python scripts/step_timeline.py /tmp/tl_$c.csv 1 > $O/${TAG}_timeline_config$c.txt 2>&1
+done
+timeout -k 10 200 python scripts/red_epilogue_cost.py 96 2> /dev/null | grep -v amdgpu.ids > $O/${TAG}_red_epilogue_cost.txt
 cd /tmp && export TMPDIR=/tmp
 # rocprofv3 kernel trace of the bench command with HIP-event brackets on every step (same kernels, same averages)
 rm -rf /tmp/prof_$TAG
-timeout -k 10 500 rocprofv3 --kernel-trace --stats -d /tmp/prof_$TAG -o trace --output-format csv -- python3 $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --profile-every 1 > $ROOT/$O/${TAG}_bench_profile_every_1.json 2> $ROOT/$O/${TAG}_rocprof.err
+timeout -k 10 500 rocprofv3 --kernel-trace --stats -d /tmp/prof_$TAG -o trace --output-format csv -- python3 $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --profile-every 1 --timeline-steps 0 > $ROOT/$O/${TAG}_bench_profile_every_1.json 2> $ROOT/$O/${TAG}_rocprof.err
 cp "$(find /tmp/prof_$TAG -name '*kernel_stats.csv' | head -1)" $ROOT/$O/${TAG}_bench_profile_every_1.kernel_stats.csv
 # heads (PE / GroupNorm / MHA / fusion) + STFT: config 3 from waveforms
 rm -rf /tmp/prof_h_$TAG
-timeout -k 10 500 rocprofv3 --kernel-trace --stats -d /tmp/prof_h_$TAG -o trace --output-format csv -- python3 $ROOT/bench.py --config 3 --stft-inputs --steps 10 --warmup 3 --no-cpu-baseline --profile-every 0 > $ROOT/$O/${TAG}_heads_bench_config3_stft.json 2> /dev/null
+timeout -k 10 500 rocprofv3 --kernel-trace --stats -d /tmp/prof_h_$TAG -o trace --output-format csv -- python3 $ROOT/bench.py --config 3 --stft-inputs --steps 10 --warmup 3 --no-cpu-baseline --profile-every 0 --timeline-steps 0 > $ROOT/$O/${TAG}_heads_bench_config3_stft.json 2> /dev/null
 cp "$(find /tmp/prof_h_$TAG -name '*kernel_stats.csv' | head -1)" $ROOT/$O/${TAG}_heads_config3_stft.kernel_stats.csv
 fi
 if [ -n "$ONLY_BENCH" ]; then cd $ROOT; echo done; exit 0; fi
@@ -48,8 +54,8 @@ traffic() {
   rm -rf /tmp/pmc_cal /tmp/pmc_RD /tmp/pmc_WRITE_SIZE
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_BUBBLE_sum -d /tmp/pmc_cal -o t --output-format csv -- python3 $ROOT/scripts/pmc_calibrate.py > /tmp/pmc_cal_expect.txt 2> /tmp/pmc_cal.err
   tail -1 /tmp/pmc_cal_expect.txt > /tmp/pmc_cal_expect.json
-  timeout -k 10 500 rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_BUBBLE_sum -d /tmp/pmc_RD -o t --output-format csv -- python3 $ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --profile-every 1 > /dev/null 2>&1
-  timeout -k 10 500 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/pmc_WRITE_SIZE -o t --output-format csv -- python3 $ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --profile-every 1 > /dev/null 2>&1
+  timeout -k 10 500 rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_BUBBLE_sum -d /tmp/pmc_RD -o t --output-format csv -- python3 $ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --profile-every 1 --timeline-steps 0 > /dev/null 2>&1
+  timeout -k 10 500 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/pmc_WRITE_SIZE -o t --output-format csv -- python3 $ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --profile-every 1 --timeline-steps 0 > /dev/null 2>&1
   python3 $ROOT/scripts/pmc_traffic.py --raw "$(find /tmp/pmc_RD -name '*counter_collection.csv' | head -1)" "$(find /tmp/pmc_WRITE_SIZE -name '*counter_collection.csv' | head -1)" $ROOT/$O/${TAG}_pmc_traffic.json 3 "$(cd $ROOT && cat .gitrev 2>/dev/null || true)" "$(find /tmp/pmc_cal -name '*counter_collection.csv' | head -1)" /tmp/pmc_cal_expect.json > $ROOT/$O/${TAG}_pmc_traffic_top.txt
 }
 traffic
@@ -57,7 +63,7 @@ if [ -n "$ONLY_TRAFFIC" ]; then cd $ROOT; cat $O/${TAG}_pmc_traffic_top.txt; ech
 # heads / STFT traffic (HBM-bound kernels of config 3 from waveforms)
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmch_$c
-  timeout -k 10 500 rocprofv3 --kernel-trace --pmc $c -d /tmp/pmch_$c -o t --output-format csv -- python3 $ROOT/bench.py --config 3 --stft-inputs --steps 3 --warmup 2 --no-cpu-baseline --profile-every 0 > /dev/null 2>&1
+  timeout -k 10 500 rocprofv3 --kernel-trace --pmc $c -d /tmp/pmch_$c -o t --output-format csv -- python3 $ROOT/bench.py --config 3 --stft-inputs --steps 3 --warmup 2 --no-cpu-baseline --profile-every 0 --timeline-steps 0 > /dev/null 2>&1
 done
 python3 $ROOT/scripts/pmc_traffic.py /tmp/pmch_FETCH_SIZE/t_counter_collection.csv /tmp/pmch_WRITE_SIZE/t_counter_collection.csv $ROOT/$O/${TAG}_heads_pmc_traffic.json 3 > /dev/null
 # SQ counters per modality (MFMA pipe utilisation per kernel, wave-level wait breakdown)
