@@ -544,6 +544,25 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p, RiderP rider) 
   conv_igemm_body<MT, NT, ROWMODE, EPI, STAGES, RED>(p, bid, lds);
 }
 
+// LDS-DMA primitive (see the LDS-DMA variant of the generic kernel further down for the protocol): lane l's 16 bytes land at
+// (wave-uniform LDS address in M0) + 16 l
+__device__ __forceinline__ void lds_dma16(i32x4 rsrc, unsigned lds_dst, unsigned voff, unsigned soff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+               :
+               : "s"(lds_dst), "v"(voff), "s"(rsrc), "s"(soff)
+               : "memory");   // (m0 cannot be named as a clobber: clang rejects it as a reserved register; nothing else in this
+                              //  kernel keeps a value in M0 -- no readlane / movrel / LDS-direct uses)
+}
+
+// Round 6: the LDS-halo kernel's WEIGHT tiles (one 32*NT x 32 tile per tap) go global -> LDS by LDS-DMA for the MT = 1 tiles -- no
+// VGPR round trip, no ds_write, the store's issue slots go to the MFMAs (scripts/ubench/kstep_cost.hip: the tile store costs the
+// K-step 3.5 % of the peak).  Measured (profiles/r06_ab_halo_dma_b.txt, r06_conv_variants_halo_dma_b.txt): steady state <1,1> +0.8 %,
+// <1,2> +2.6 %, <1,3> +0.7 %; <2,x> -0.4 ... -1.2 % (they stay register-staged); one-stream conv stage of the bench +1.1 points
+// (3 of 3), three-stream step +-0.  -DTBN_HALO_DMA_B=0 restores the register-staged form for every tile.
+#ifndef TBN_HALO_DMA_B
+#define TBN_HALO_DMA_B 1
+#endif
+
 // ------------------------------------------------------------------------------------------
 // 3x3 / stride 1 / pad 1 convolution (forward of such a layer, and its data gradient, which has the same form) with
 // the INPUT PATCH STAGED ONCE PER 32-CHANNEL CHUNK.  The generic body above gathers an im2col A tile per filter tap:
@@ -625,6 +644,7 @@ __device__ __forceinline__ void conv_halo_body(const ConvP& p, const int bid, fl
     for (int j = 0; j < NJ; ++j)
       if (r0 + 32 * j < HR) *reinterpret_cast<float4*>(&As[(r0 + 32 * j) * LDT + c4 * 4]) = ha[j];
   };
+  constexpr bool DMAB = (TBN_HALO_DMA_B != 0) && MT == 1;
   float4 rb[NT];
   unsigned b_voff[NT];
 #pragma unroll
@@ -639,6 +659,29 @@ __device__ __forceinline__ void conv_halo_body(const ConvP& p, const int bid, fl
 #pragma unroll
     for (int i = 0; i < NT; ++i) *reinterpret_cast<float4*>(&Bs[(r0 + 32 * i) * LDT + c4 * 4]) = rb[i];
   };
+  // DMAB: the weight tile of a tap goes global -> LDS directly (no VGPR round trip, no ds_write): rows are 128 B, unpadded,
+  // 16-B slot q of row r at slot q ^ ((r >> 1) & 7) (the swizzle of conv_dma_body, applied on the source address and again
+  // on the fragment read); a wave instruction writes 8 rows
+  const int dr = lane >> 3, dslot = lane & 7;
+  unsigned bd_voff[NT], fb_addr[NT][4];
+#pragma unroll
+  for (int i = 0; i < NT; ++i) {
+    const int r = (wave + 4 * i) * 8 + dr;
+    bd_voff[i] = (unsigned)(n0 + r) * (unsigned)p.Krow * 4u + (unsigned)((dslot ^ ((r >> 1) & 7)) << 4);
+  }
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int r = j * 32 + lrow;
+#pragma unroll
+    for (int kg = 0; kg < 4; ++kg) fb_addr[j][kg] = (unsigned)(r * 128 + (((2 * kg + lhalf) ^ ((r >> 1) & 7)) << 4));
+  }
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
+  const unsigned ldsB = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)reinterpret_cast<char*>(Bs0));
+  auto dma_b = [&](int t, int c0, int stage) {
+    const unsigned koff = (unsigned)__builtin_amdgcn_readfirstlane((t * p.Cin + c0) * 4);
+#pragma unroll
+    for (int i = 0; i < NT; ++i) lds_dma16(wt_rsrc, ldsB + (unsigned)(stage * BN * 128 + (wv + 4 * i) * 1024), bd_voff[i], koff);
+  };
 
   f32x16 acc[MT][NT];
 #pragma unroll
@@ -650,10 +693,16 @@ __device__ __forceinline__ void conv_halo_body(const ConvP& p, const int bid, fl
 
   // prologue: zero row, halo of chunk 0, B tile of (tap 0, chunk 0)
   load_halo(0);
-  load_b(0, 0);
+  if (DMAB)
+    dma_b(0, 0, 0);
+  else
+    load_b(0, 0);
   if (tid < LDT) As[HR * LDT + tid] = 0.f;
   store_halo(0);
-  store_b(Bs0);
+  if (DMAB)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else
+    store_b(Bs0);
   __syncthreads();
 
   const int nchunks = p.Cin >> 5;
@@ -671,15 +720,23 @@ __device__ __forceinline__ void conv_halo_body(const ConvP& p, const int bid, fl
 #pragma unroll
     for (int t = 0; t < 9; ++t, ++ks) {
       const bool more = NEXT || t < 8;
-      if (more) load_b(t < 8 ? t + 1 : 0, t < 8 ? c * 32 : (c + 1) * 32);
+      if (more) {
+        // DMAB: straight into the other stage (last read in the previous tap: every wave is past that tap's barrier)
+        if (DMAB)
+          dma_b(t < 8 ? t + 1 : 0, t < 8 ? c * 32 : (c + 1) * 32, (ks + 1) & 1);
+        else
+          load_b(t < 8 ? t + 1 : 0, t < 8 ? c * 32 : (c + 1) * 32);
+      }
       const float* Bs = Bs0 + (ks & 1) * (BN * LDT);
+      const char* Bd = reinterpret_cast<const char*>(Bs0) + (ks & 1) * (BN * 128);
       float4 fa[2][MT], fb[2][NT];
       auto frag_load = [&](int buf, int kg) {
 #pragma unroll
         for (int i = 0; i < MT; ++i) fa[buf][i] = *reinterpret_cast<const float4*>(As_b + fa_off[i][t] + kg * 32);
 #pragma unroll
         for (int j = 0; j < NT; ++j)
-          fb[buf][j] = *reinterpret_cast<const float4*>(&Bs[(j * 32 + lrow) * LDT + kg * 8 + lhalf * 4]);
+          fb[buf][j] = DMAB ? *reinterpret_cast<const float4*>(Bd + fb_addr[j][kg])
+                            : *reinterpret_cast<const float4*>(&Bs[(j * 32 + lrow) * LDT + kg * 8 + lhalf * 4]);
       };
       auto mfma_group = [&](int buf) {
 #pragma unroll
@@ -713,7 +770,11 @@ __device__ __forceinline__ void conv_halo_body(const ConvP& p, const int bid, fl
         __builtin_amdgcn_sched_group_barrier(0x008, 2 * NM, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
-      if (more) store_b(Bs0 + ((ks + 1) & 1) * (BN * LDT));
+      if (DMAB)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA of the next tap's weights has landed (and so has
+                                                           // the next chunk's halo prefetch issued at the top of tap 0)
+      else if (more)
+        store_b(Bs0 + ((ks + 1) & 1) * (BN * LDT));
       __syncthreads();
     }
     if (NEXT) {   // every wave is past its last read of this chunk's halo (barrier above)
@@ -746,13 +807,6 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(ConvP p, RiderP rider) {
 // `s_waitcnt vmcnt(0)` in front of the next fragment read -- draining the prefetch it is supposed to overlap.  The
 // asm statement is invisible to that bookkeeping; the wait is placed by hand before the barrier that publishes the
 // stage (cdna_hip_programming.md 5.7: M0 is written in the same statement that uses it).
-__device__ __forceinline__ void lds_dma16(i32x4 rsrc, unsigned lds_dst, unsigned voff, unsigned soff) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-               :
-               : "s"(lds_dst), "v"(voff), "s"(rsrc), "s"(soff)
-               : "memory");   // (m0 cannot be named as a clobber: clang rejects it as a reserved register; nothing else in this
-                              //  kernel keeps a value in M0 -- no readlane / movrel / LDS-direct uses)
-}
 
 template <int MT, int NT, int EPI, bool RED>
 __device__ __forceinline__ void conv_dma_body(const ConvP& p, const int bid, float* lds) {
@@ -1354,6 +1408,206 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
 
   // cross-wave reduction, one 32x32 sub-tile at a time: red[wave][32*32]
   float* red = lds;
+  float* obase = p.out + (size_t)split * p.Cout * p.K;
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = 8 * (e >> 2) + 4 * lhalf + (e & 3);
+        float v = acc[i][j][0][e];
+#pragma unroll
+        for (int q = 1; q < KS; ++q) v += acc[i][j][q][e];
+        red[wave * 1024 + row * 32 + lrow] = v;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int el = tid + 256 * t;
+        const float v = (red[el] + red[1024 + el]) + (red[2048 + el] + red[3072 + el]);
+        const int row = el >> 5, col = el & 31;
+        const int co = co0 + i * 32 + row, ci = ci0 + j * 32 + col;
+        if (co < p.Cout && ci < p.Cin) obase[(size_t)co * p.K + tap * p.Cin + ci] = v;
+      }
+      __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// LDS-DMA form of the weight-gradient kernel (round 6, -DTBN_WGRAD_DMA=1): the dy / x rows of a step go global -> LDS
+// directly (buffer_load_dwordx4 ... lds: no VGPR round trip, no ds_write -- the register-staged loop issues 4 (MT + NT)
+// loads AND as many ds_write_b128 per 16 MT NT MFMAs, and scripts/ubench/kstep_cost.hip prices one store per 16 MFMAs at
+// 3.5 % of the peak).  Same lane -> row ownership, same incremental row addressing, same accumulator rotation, same
+// cross-wave reduction as conv_wgrad_kernel, so the results are bit-identical to it.
+// LDS layout: a DMA instruction writes lane l's 16 bytes at (wave-uniform base) + 16 l, and lane l owns row l >> 2 and the
+// 16-byte piece l & 3 of a 16-float column block -- so instruction k of a step fills one [16 rows][16 floats] block
+// (1 KB, contiguous).  Blocks are 288 floats apart (odd blocks start 32 banks further): a fragment read -- lanes 0-15 /
+// 16-31 in two neighbouring blocks, lanes 32-63 one k row on -- touches 64 different banks.  Two stages per wave (the
+// DMA of step it + 1 flies under the MFMAs of step it; the tiles stay wave-private: no workgroup barrier in the loop).
+#ifndef TBN_WGRAD_DMA
+#define TBN_WGRAD_DMA 0
+#endif
+template <int MT, int NT, int MODE>
+__global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgradP p) {
+  constexpr bool ROWMODE = (MODE == 1);
+  constexpr int KR = 16;                             // pixel rows per wave step
+  constexpr int BS = 288;                            // floats between column blocks (256 + 32: odd blocks shifted by 32 banks)
+  constexpr int AI = 2 * MT, BI = 2 * NT;            // 16-float column blocks of the dy / x tile
+  constexpr int WS = (AI + BI) * BS;                 // floats per wave and stage
+  extern __shared__ __attribute__((aligned(16))) float wlds[];   // [4 waves][2 stages][WS]; >= 4 * 1024 floats (reduction)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
+
+  int b;
+  {
+    const int nb = gridDim.x, bid = blockIdx.x;
+    const int q8 = nb >> 3, r8 = nb & 7, xcd = bid & 7, idx = bid >> 3;
+    b = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+  }
+  const int tco = b % p.tiles_co;
+  b /= p.tiles_co;
+  const int tci = b % p.tiles_ci;
+  b /= p.tiles_ci;
+  const int tap = b % p.taps;
+  const int split = b / p.taps;
+  const int co0 = tco * 32 * MT, ci0 = tci * 32 * NT;
+  int r, s;
+  if (ROWMODE) {
+    r = tap;
+    s = 0;
+  } else {
+    r = tap / p.S;
+    s = tap - r * p.S;
+  }
+  const int pbeg = split * p.rows_per_split;
+
+  constexpr int KS = (MT * NT >= 4) ? 1 : (MT * NT == 1 ? 4 : 2);
+  f32x16 acc[MT][NT][KS];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int q = 0; q < KS; ++q)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][q][e] = 0.f;
+
+  const int lrow16 = lane >> 2, lq = lane & 3;
+  const i32x4 dy_rsrc = make_rsrc(p.dy, p.dy_bytes);
+  const i32x4 x_rsrc = make_rsrc(p.x, p.x_bytes);
+  const unsigned m0 = (unsigned)(pbeg + wave * KR + lrow16);
+  unsigned dyo = (m0 * (unsigned)p.dy_ld + (unsigned)(co0 + lq * 4)) * 4u;
+  const unsigned dy_step = (unsigned)(4 * KR * p.dy_ld) * 4u;
+  unsigned xo = 0, pp = 0, fb = 0;
+  unsigned rm_off[BI];
+  if (MODE == 2) {
+    xo = (m0 * (unsigned)p.x_ld + (unsigned)(ci0 + lq * 4)) * 4u;
+  } else {
+    const uint32_t n = fdiv(m0, p.div_ohw);
+    pp = m0 - n * p.div_ohw.d;
+    fb = n * p.frame_bytes + (ROWMODE ? 0u : (unsigned)(ci0 + lq * 4) * 4u);
+    if (ROWMODE) {
+#pragma unroll
+      for (int k = 0; k < BI; ++k) {
+        const int cc = ci0 + lq * 4 + 16 * k;
+        const uint32_t f = (uint32_t)cc >> 2, t = fdiv(f, p.div_rl4);
+        rm_off[k] = (t * (uint32_t)(p.W * p.cp) + (f - t * p.div_rl4.d) * 4u) * 4u;
+      }
+    }
+  }
+  const unsigned x_step = (unsigned)(4 * KR * p.x_ld) * 4u;
+  const int tap_y = r - p.pad, tap_x = s - p.pad;
+  const unsigned xld4 = (unsigned)p.x_ld * 4u;
+  // (the low 32 bits of a generic pointer into LDS are the LDS byte offset)
+  const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)reinterpret_cast<char*>(wlds)) +
+                        (unsigned)(wv * 2 * WS) * 4u;
+  // one step's rows straight into stage `stage` of this wave: the row state advances exactly as in conv_wgrad_kernel
+  auto dma_tiles = [&](int stage) {
+    const unsigned st = lds0 + (unsigned)(stage * WS) * 4u;
+#pragma unroll
+    for (int k = 0; k < AI; ++k) lds_dma16(dy_rsrc, st + (unsigned)(k * BS) * 4u, dyo + 64u * k, 0u);
+    dyo += dy_step;
+    if (MODE == 2) {
+#pragma unroll
+      for (int k = 0; k < BI; ++k) lds_dma16(x_rsrc, st + (unsigned)((AI + k) * BS) * 4u, xo + 64u * k, 0u);
+      xo += x_step;
+    } else {
+      const unsigned oy = p.mul_ow != 0u ? __umulhi(pp, p.mul_ow) : pp;
+      const unsigned ox = pp - __umul24(oy, (unsigned)p.OW);
+      if (MODE == 0) {
+        const unsigned iy = __umul24(oy, (unsigned)p.stride) + (unsigned)tap_y;
+        const unsigned ix = __umul24(ox, (unsigned)p.stride) + (unsigned)tap_x;
+        const bool ok = (iy < (unsigned)p.H) && (ix < (unsigned)p.W);
+        const unsigned off = fb + __umul24(__umul24(iy, (unsigned)p.W) + ix, xld4);
+        const unsigned voff = ok ? off : TBN_OOB;      // out-of-image tap: the DMA writes zeros
+#pragma unroll
+        for (int k = 0; k < BI; ++k) lds_dma16(x_rsrc, st + (unsigned)((AI + k) * BS) * 4u, voff + 64u * k, 0u);
+      } else {
+        const unsigned off = fb + __umul24(oy, p.row_step) + __umul24(ox, p.col_step);
+#pragma unroll
+        for (int k = 0; k < BI; ++k) lds_dma16(x_rsrc, st + (unsigned)((AI + k) * BS) * 4u, off + rm_off[k], 0u);
+      }
+      pp += p.r64;
+      const bool wrap = pp >= p.div_ohw.d;
+      pp = wrap ? pp - p.div_ohw.d : pp;
+      fb += wrap ? p.fb_hi : p.fb_lo;
+    }
+  };
+
+  const int nsteps = (p.rows_per_split + 4 * KR - 1) / (4 * KR);
+  const int lrow = lane & 31, lhalf = lane >> 5;
+  // this lane's fragment element of k row 0: block (lrow >> 4) of a 32-column sub-tile, column lrow & 15, k row lhalf
+  const float* Abase = wlds + wv * 2 * WS + (lrow >> 4) * BS + (lrow & 15) + lhalf * 16;
+  const float* Bbase = Abase + AI * BS;
+  auto compute = [&](const int stage) {
+    const float* At = Abase + stage * WS;
+    const float* Bt = Bbase + stage * WS;
+    float a[2][MT], bb[2][NT];
+    auto frag = [&](int buf, int kp) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i) a[buf][i] = At[i * 2 * BS + kp * 32];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) bb[buf][j] = Bt[j * 2 * BS + kp * 32];
+    };
+    frag(0, 0);
+#pragma unroll
+    for (int kp = 0; kp < KR / 2; ++kp) {
+      if (kp + 1 < KR / 2) frag((kp + 1) & 1, kp + 1);
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          acc[i][j][kp % KS] =
+              __builtin_amdgcn_mfma_f32_32x32x2f32(a[kp & 1][i], bb[kp & 1][j], acc[i][j][kp % KS], 0, 0, 0);
+    }
+    {
+      constexpr int NM = MT * NT;
+      constexpr int NRD = MT + NT;   // (blocks of one operand are 2 * BS floats apart: no ds_read2 merge assumed)
+      __builtin_amdgcn_sched_group_barrier(0x100, 2 * NRD, 0);
+#pragma unroll
+      for (int g = 0; g < KR / 2 - 2; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 2 * NM, 0);
+    }
+  };
+  dma_tiles(0);
+  for (int it = 0; it < nsteps; it += 2) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the rows of step `it` have landed in stage 0
+    if (it + 1 < nsteps) dma_tiles(1);                     // stage 1 was last read in step it - 1: those reads have returned
+    compute(0);
+    __builtin_amdgcn_wave_barrier();
+    if (it + 1 >= nsteps) break;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (it + 2 < nsteps) dma_tiles(0);
+    compute(1);
+    __builtin_amdgcn_wave_barrier();
+  }
+  __syncthreads();  // the reduction buffer below overlays every wave's tiles
+
+  float* red = wlds;
   float* obase = p.out + (size_t)split * p.Cout * p.K;
 #pragma unroll
   for (int i = 0; i < MT; ++i)
@@ -2006,7 +2260,28 @@ int tbn_launch_conv_pair(ConvP a, ConvP b, int variant, int mt, int nt, hipStrea
 }
 
 template <int MT, int NT, int MODE>
+static int launch_wgrad_dma(const WgradP& p, int blocks, hipStream_t st) {
+  constexpr size_t bytes = (size_t)4 * 2 * (2 * MT + 2 * NT) * 288 * sizeof(float);
+  static_assert(bytes >= 4 * 1024 * sizeof(float) && bytes <= 160 * 1024, "wgrad DMA tile does not fit the LDS");
+  static bool raised = false;      // per instantiation: raise the dynamic-LDS limit once
+  if (bytes > 64 * 1024 && !raised) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_dma_kernel<MT, NT, MODE>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+      tbn_set_error("conv_wgrad: cannot raise the dynamic LDS limit");
+      return TBN_ERR_LAUNCH;
+    }
+    raised = true;
+  }
+  TBN_LAUNCH((conv_wgrad_dma_kernel<MT, NT, MODE>), dim3(blocks), dim3(256), bytes, st, p);
+  return TBN_OK;
+}
+
+template <int MT, int NT, int MODE>
 static void launch_wgrad(const WgradP& p, int blocks, hipStream_t st) {
+#if TBN_WGRAD_DMA && !TBN_DIAG && !TBN_ABLATE
+  (void)launch_wgrad_dma<MT, NT, MODE>(p, blocks, st);
+  return;
+#endif
   // experiment knob (A/B runs only): unused dynamic LDS caps the workgroups per CU (the 64 x 64 tile needs 64 registers and
   // 34 KB of LDS: four per CU; each split's 54 tile x tap workgroups share an x / dy slab through the XCD's 4-MB L2)
   // (clamped to what still launches: 64 KB of dynamic LDS minus the kernel's 34 KB of static LDS)
