@@ -1434,206 +1434,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
     }
 }
 
-// ------------------------------------------------------------------------------------------
-// LDS-DMA form of the weight-gradient kernel (round 6, -DTBN_WGRAD_DMA=1): the dy / x rows of a step go global -> LDS
-// directly (buffer_load_dwordx4 ... lds: no VGPR round trip, no ds_write -- the register-staged loop issues 4 (MT + NT)
-// loads AND as many ds_write_b128 per 16 MT NT MFMAs, and scripts/ubench/kstep_cost.hip prices one store per 16 MFMAs at
-// 3.5 % of the peak).  Same lane -> row ownership, same incremental row addressing, same accumulator rotation, same
-// cross-wave reduction as conv_wgrad_kernel, so the results are bit-identical to it.
-// LDS layout: a DMA instruction writes lane l's 16 bytes at (wave-uniform base) + 16 l, and lane l owns row l >> 2 and the
-// 16-byte piece l & 3 of a 16-float column block -- so instruction k of a step fills one [16 rows][16 floats] block
-// (1 KB, contiguous).  Blocks are 288 floats apart (odd blocks start 32 banks further): a fragment read -- lanes 0-15 /
-// 16-31 in two neighbouring blocks, lanes 32-63 one k row on -- touches 64 different banks.  Two stages per wave (the
-// DMA of step it + 1 flies under the MFMAs of step it; the tiles stay wave-private: no workgroup barrier in the loop).
-#ifndef TBN_WGRAD_DMA
-#define TBN_WGRAD_DMA 0
-#endif
-template <int MT, int NT, int MODE>
-__global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgradP p) {
-  constexpr bool ROWMODE = (MODE == 1);
-  constexpr int KR = 16;                             // pixel rows per wave step
-  constexpr int BS = 288;                            // floats between column blocks (256 + 32: odd blocks shifted by 32 banks)
-  constexpr int AI = 2 * MT, BI = 2 * NT;            // 16-float column blocks of the dy / x tile
-  constexpr int WS = (AI + BI) * BS;                 // floats per wave and stage
-  extern __shared__ __attribute__((aligned(16))) float wlds[];   // [4 waves][2 stages][WS]; >= 4 * 1024 floats (reduction)
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wv = __builtin_amdgcn_readfirstlane(wave);
-
-  int b;
-  {
-    const int nb = gridDim.x, bid = blockIdx.x;
-    const int q8 = nb >> 3, r8 = nb & 7, xcd = bid & 7, idx = bid >> 3;
-    b = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
-  }
-  const int tco = b % p.tiles_co;
-  b /= p.tiles_co;
-  const int tci = b % p.tiles_ci;
-  b /= p.tiles_ci;
-  const int tap = b % p.taps;
-  const int split = b / p.taps;
-  const int co0 = tco * 32 * MT, ci0 = tci * 32 * NT;
-  int r, s;
-  if (ROWMODE) {
-    r = tap;
-    s = 0;
-  } else {
-    r = tap / p.S;
-    s = tap - r * p.S;
-  }
-  const int pbeg = split * p.rows_per_split;
-
-  constexpr int KS = (MT * NT >= 4) ? 1 : (MT * NT == 1 ? 4 : 2);
-  f32x16 acc[MT][NT][KS];
-#pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-      for (int q = 0; q < KS; ++q)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[i][j][q][e] = 0.f;
-
-  const int lrow16 = lane >> 2, lq = lane & 3;
-  const i32x4 dy_rsrc = make_rsrc(p.dy, p.dy_bytes);
-  const i32x4 x_rsrc = make_rsrc(p.x, p.x_bytes);
-  const unsigned m0 = (unsigned)(pbeg + wave * KR + lrow16);
-  unsigned dyo = (m0 * (unsigned)p.dy_ld + (unsigned)(co0 + lq * 4)) * 4u;
-  const unsigned dy_step = (unsigned)(4 * KR * p.dy_ld) * 4u;
-  unsigned xo = 0, pp = 0, fb = 0;
-  unsigned rm_off[BI];
-  if (MODE == 2) {
-    xo = (m0 * (unsigned)p.x_ld + (unsigned)(ci0 + lq * 4)) * 4u;
-  } else {
-    const uint32_t n = fdiv(m0, p.div_ohw);
-    pp = m0 - n * p.div_ohw.d;
-    fb = n * p.frame_bytes + (ROWMODE ? 0u : (unsigned)(ci0 + lq * 4) * 4u);
-    if (ROWMODE) {
-#pragma unroll
-      for (int k = 0; k < BI; ++k) {
-        const int cc = ci0 + lq * 4 + 16 * k;
-        const uint32_t f = (uint32_t)cc >> 2, t = fdiv(f, p.div_rl4);
-        rm_off[k] = (t * (uint32_t)(p.W * p.cp) + (f - t * p.div_rl4.d) * 4u) * 4u;
-      }
-    }
-  }
-  const unsigned x_step = (unsigned)(4 * KR * p.x_ld) * 4u;
-  const int tap_y = r - p.pad, tap_x = s - p.pad;
-  const unsigned xld4 = (unsigned)p.x_ld * 4u;
-  // (the low 32 bits of a generic pointer into LDS are the LDS byte offset)
-  const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)reinterpret_cast<char*>(wlds)) +
-                        (unsigned)(wv * 2 * WS) * 4u;
-  // one step's rows straight into stage `stage` of this wave: the row state advances exactly as in conv_wgrad_kernel
-  auto dma_tiles = [&](int stage) {
-    const unsigned st = lds0 + (unsigned)(stage * WS) * 4u;
-#pragma unroll
-    for (int k = 0; k < AI; ++k) lds_dma16(dy_rsrc, st + (unsigned)(k * BS) * 4u, dyo + 64u * k, 0u);
-    dyo += dy_step;
-    if (MODE == 2) {
-#pragma unroll
-      for (int k = 0; k < BI; ++k) lds_dma16(x_rsrc, st + (unsigned)((AI + k) * BS) * 4u, xo + 64u * k, 0u);
-      xo += x_step;
-    } else {
-      const unsigned oy = p.mul_ow != 0u ? __umulhi(pp, p.mul_ow) : pp;
-      const unsigned ox = pp - __umul24(oy, (unsigned)p.OW);
-      if (MODE == 0) {
-        const unsigned iy = __umul24(oy, (unsigned)p.stride) + (unsigned)tap_y;
-        const unsigned ix = __umul24(ox, (unsigned)p.stride) + (unsigned)tap_x;
-        const bool ok = (iy < (unsigned)p.H) && (ix < (unsigned)p.W);
-        const unsigned off = fb + __umul24(__umul24(iy, (unsigned)p.W) + ix, xld4);
-        const unsigned voff = ok ? off : TBN_OOB;      // out-of-image tap: the DMA writes zeros
-#pragma unroll
-        for (int k = 0; k < BI; ++k) lds_dma16(x_rsrc, st + (unsigned)((AI + k) * BS) * 4u, voff + 64u * k, 0u);
-      } else {
-        const unsigned off = fb + __umul24(oy, p.row_step) + __umul24(ox, p.col_step);
-#pragma unroll
-        for (int k = 0; k < BI; ++k) lds_dma16(x_rsrc, st + (unsigned)((AI + k) * BS) * 4u, off + rm_off[k], 0u);
-      }
-      pp += p.r64;
-      const bool wrap = pp >= p.div_ohw.d;
-      pp = wrap ? pp - p.div_ohw.d : pp;
-      fb += wrap ? p.fb_hi : p.fb_lo;
-    }
-  };
-
-  const int nsteps = (p.rows_per_split + 4 * KR - 1) / (4 * KR);
-  const int lrow = lane & 31, lhalf = lane >> 5;
-  // this lane's fragment element of k row 0: block (lrow >> 4) of a 32-column sub-tile, column lrow & 15, k row lhalf
-  const float* Abase = wlds + wv * 2 * WS + (lrow >> 4) * BS + (lrow & 15) + lhalf * 16;
-  const float* Bbase = Abase + AI * BS;
-  auto compute = [&](const int stage) {
-    const float* At = Abase + stage * WS;
-    const float* Bt = Bbase + stage * WS;
-    float a[2][MT], bb[2][NT];
-    auto frag = [&](int buf, int kp) {
-#pragma unroll
-      for (int i = 0; i < MT; ++i) a[buf][i] = At[i * 2 * BS + kp * 32];
-#pragma unroll
-      for (int j = 0; j < NT; ++j) bb[buf][j] = Bt[j * 2 * BS + kp * 32];
-    };
-    frag(0, 0);
-#pragma unroll
-    for (int kp = 0; kp < KR / 2; ++kp) {
-      if (kp + 1 < KR / 2) frag((kp + 1) & 1, kp + 1);
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-          acc[i][j][kp % KS] =
-              __builtin_amdgcn_mfma_f32_32x32x2f32(a[kp & 1][i], bb[kp & 1][j], acc[i][j][kp % KS], 0, 0, 0);
-    }
-    {
-      constexpr int NM = MT * NT;
-      constexpr int NRD = MT + NT;   // (blocks of one operand are 2 * BS floats apart: no ds_read2 merge assumed)
-      __builtin_amdgcn_sched_group_barrier(0x100, 2 * NRD, 0);
-#pragma unroll
-      for (int g = 0; g < KR / 2 - 2; ++g) {
-        __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
-      }
-      __builtin_amdgcn_sched_group_barrier(0x008, 2 * NM, 0);
-    }
-  };
-  dma_tiles(0);
-  for (int it = 0; it < nsteps; it += 2) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the rows of step `it` have landed in stage 0
-    if (it + 1 < nsteps) dma_tiles(1);                     // stage 1 was last read in step it - 1: those reads have returned
-    compute(0);
-    __builtin_amdgcn_wave_barrier();
-    if (it + 1 >= nsteps) break;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (it + 2 < nsteps) dma_tiles(0);
-    compute(1);
-    __builtin_amdgcn_wave_barrier();
-  }
-  __syncthreads();  // the reduction buffer below overlays every wave's tiles
-
-  float* red = wlds;
-  float* obase = p.out + (size_t)split * p.Cout * p.K;
-#pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row = 8 * (e >> 2) + 4 * lhalf + (e & 3);
-        float v = acc[i][j][0][e];
-#pragma unroll
-        for (int q = 1; q < KS; ++q) v += acc[i][j][q][e];
-        red[wave * 1024 + row * 32 + lrow] = v;
-      }
-      __syncthreads();
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int el = tid + 256 * t;
-        const float v = (red[el] + red[1024 + el]) + (red[2048 + el] + red[3072 + el]);
-        const int row = el >> 5, col = el & 31;
-        const int co = co0 + i * 32 + row, ci = ci0 + j * 32 + col;
-        if (co < p.Cout && ci < p.Cin) obase[(size_t)co * p.K + tap * p.Cin + ci] = v;
-      }
-      __syncthreads();
-    }
-}
-
 // Sums the split-K slabs of a weight gradient.  256 threads = (256 / SG) float4 outputs x SG slab lanes: lane g adds
 // slabs g, g+SG, ... (two independent chains), the SG partial sums are combined through LDS in fixed order
 // (deterministic).  SG = 16 for many slabs of a small matrix (the 7x7 stem: ~110 slabs of 57 KB) so that the
@@ -2260,28 +2060,11 @@ int tbn_launch_conv_pair(ConvP a, ConvP b, int variant, int mt, int nt, hipStrea
 }
 
 template <int MT, int NT, int MODE>
-static int launch_wgrad_dma(const WgradP& p, int blocks, hipStream_t st) {
-  constexpr size_t bytes = (size_t)4 * 2 * (2 * MT + 2 * NT) * 288 * sizeof(float);
-  static_assert(bytes >= 4 * 1024 * sizeof(float) && bytes <= 160 * 1024, "wgrad DMA tile does not fit the LDS");
-  static bool raised = false;      // per instantiation: raise the dynamic-LDS limit once
-  if (bytes > 64 * 1024 && !raised) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_dma_kernel<MT, NT, MODE>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
-      tbn_set_error("conv_wgrad: cannot raise the dynamic LDS limit");
-      return TBN_ERR_LAUNCH;
-    }
-    raised = true;
-  }
-  TBN_LAUNCH((conv_wgrad_dma_kernel<MT, NT, MODE>), dim3(blocks), dim3(256), bytes, st, p);
-  return TBN_OK;
-}
-
-template <int MT, int NT, int MODE>
 static void launch_wgrad(const WgradP& p, int blocks, hipStream_t st) {
-#if TBN_WGRAD_DMA && !TBN_DIAG && !TBN_ABLATE
-  (void)launch_wgrad_dma<MT, NT, MODE>(p, blocks, st);
-  return;
-#endif
+  // (round 6: an LDS-DMA form of this kernel -- dy / x rows global -> LDS without the VGPR round trip, two stages per wave,
+  //  bit-identical results, commit 2773a1b -- measured 7 % SLOWER per launch, 499 -> 538 us on conv2_3x3: two stages of the
+  //  64 x 64 tile need 74 KB of LDS = two workgroups per CU instead of four, and a DMA issued one step ahead has 0.85 us to land;
+  //  profiles/r06_ab_wgrad_dma.txt.  Removed.)
   // experiment knob (A/B runs only): unused dynamic LDS caps the workgroups per CU (the 64 x 64 tile needs 64 registers and
   // 34 KB of LDS: four per CU; each split's 54 tile x tap workgroups share an x / dy slab through the XCD's 4-MB L2)
   // (clamped to what still launches: 64 KB of dynamic LDS minus the kernel's 34 KB of static LDS)
