@@ -640,6 +640,31 @@ def test_torch_fp32_cpu_norm_of_a_backbone_sized_gradient_is_low():
         assert abs(blocked - n64) / n64 < 1e-6, (name, blocked, n64)
 
 
+def test_shipped_library_and_models_read_no_environment_knobs():
+    """round-5 verdict item 7: A/B knobs exist only in a -DTBN_EXPERIMENT=1 build.  The shipped libtbn_hip.so does not even IMPORT
+    getenv (every knob folds to its default at compile time: csrc/tbn_common.h), says so in tbn_version() (bit 16 clear), and the
+    Python product reads the environment in exactly two documented places: the library override for diagnostic builds
+    (TBN_LIB, _lib.py) and the opt-in plan cache (TBN_PLAN_CACHE, bn_inception.py) -- core/models/model.py reads none."""
+    import re
+    import subprocess
+    from attention_based_tbn_amd import _lib
+    if os.environ.get("TBN_LIB"):
+        pytest.skip("TBN_LIB points at a diagnostic / experiment build")
+    assert _lib.lib().tbn_version() & 0x10000 == 0
+    syms = subprocess.run(["nm", "-D", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "getenv" not in syms and "tbn_env_int" not in syms, [l for l in syms.splitlines() if "env" in l]
+    pkg = os.path.join(ROOT, "attention_based_tbn_amd")
+    hits = []
+    for d, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py") and f != "build.py":
+                for i, line in enumerate(open(os.path.join(d, f)), 1):
+                    if re.search(r"os\.environ|getenv", line):
+                        hits.append((os.path.relpath(os.path.join(d, f), pkg), re.findall(r"TBN_[A-Z_]+", line)))
+    assert all(f in ("_lib.py", os.path.join("core", "models", "bn_inception.py")) for f, _ in hits), hits
+    assert {k for _, ks in hits for k in ks} <= {"TBN_LIB", "TBN_PLAN_CACHE"}, hits
+
+
 def test_plan_create_accepts_exactly_the_sizes_the_reference_graph_accepts():
     """inception_3c / 4e concatenate stride-2 conv branches (floor) with a ceil-mode max pool: for some input sizes
     the reference's torch.cat raises.  The engine plan must refuse those sizes (it would otherwise write a pooled

@@ -942,8 +942,17 @@ def test_captured_lone_backbone_train_step_replays_like_eager():
     torch.cuda.synchronize()
     graph = torch.cuda.CUDAGraph()
     net.zero_grad(set_to_none=True)
+    # the library's kernel timeline may be ON while a step is captured (round-5 advisor): launches inside the capture must not
+    # carry timeline events (an event-carrying dispatch invalidates a capture) -- they are simply absent from the timeline
+    from attention_based_tbn_amd._lib import lib
+    lib().tbn_timeline_enable(1)
     with torch.cuda.graph(graph):
         static_out = step()
+    lib().tbn_timeline_enable(0)
+    import tempfile
+    with tempfile.NamedTemporaryFile(suffix=".csv") as tf:
+        assert lib().tbn_timeline_dump(tf.name.encode()) == 0
+        assert len(open(tf.name).read().splitlines()) == 1          # the header only: nothing was recorded inside the capture
     static_grad = net.flat_weight.grad        # allocated inside the capture: rewritten by every replay
     x.copy_(torch.randn(x.shape, generator=torch.Generator().manual_seed(5)).to(DEV))
     graph.replay()
