@@ -1521,7 +1521,10 @@ int tbn_backbone_autotune(tbn_backbone_plan* P, int training, const tbn_backbone
   //   TBN_TUNE_MIN_TILE=n  candidates whose wave tile has fewer than n 32x32 sub-tiles are skipped where a larger tile
   //                        exists (round-5 verdict item 1A: force the <1,1> class onto <1,2> / <2,1> / <2,2>)
   //   TBN_TUNE_CORUN=k     every candidate is timed as k+1 concurrent copies (k helper streams beside the launch stream):
-  //                        what a launch costs in CU-time beside neighbours, not alone on an empty device
+  //                        what a launch costs in CU-time beside neighbours, not alone on an empty device.  The helper
+  //                        streams run the SAME candidate sequence in lockstep -- forked once in front of a GEMM's batch of
+  //                        candidates and joined once behind it: a fork / join per candidate (the first form of this knob)
+  //                        put ~70 us of cross-stream waits into every 50 - 150-us bracket and made the ranking noise
   static const int min_tile = tbn_env_int("TBN_TUNE_MIN_TILE", 1, 1, 4);
   static const int corun = tbn_env_int("TBN_TUNE_CORUN", 0, 0, 3);
   hipStream_t hs[3] = {nullptr, nullptr, nullptr};
@@ -1575,6 +1578,7 @@ int tbn_backbone_autotune(tbn_backbone_plan* P, int training, const tbn_backbone
       static const int force_halo = tbn_env_int("TBN_FORCE_HALO", -1, -1, 1);   // tests: 0 / 1
       Cand cand[kMaxCand];
       int ncand = 0;
+      corun_fork();
       for (int mt = 1; mt <= 2 && rc == TBN_OK; ++mt)
         for (int nt = 1; nt <= 4 && rc == TBN_OK; ++nt)
           for (int stg = 0; stg <= 4 && rc == TBN_OK; ++stg) {   // 0: LDS-halo kernel (3x3 / stride-1 layers), 3: LDS-DMA,
@@ -1596,16 +1600,17 @@ int tbn_backbone_autotune(tbn_backbone_plan* P, int training, const tbn_backbone
             p.stages = stg == 3 ? 2 : (stg == 4 ? 1 : stg);
             if (ncand >= kMaxCand) continue;
             if (mt * nt < min_tile && (p.Cout > 32 || mt < 2) && !(c.stem && pass == 0)) continue;   // experiment: no small tiles
-            rc = tbn_launch_conv(p, c.stem && pass == 0, mt, nt, st);     // untimed first run of the candidate
-            corun_fork();
+            for (int k = 0; k < corun && rc == TBN_OK; ++k)     // the copies: same two launches, same order, on the helper streams
+              for (int rep = 0; rep < 2 && rc == TBN_OK; ++rep) rc = tbn_launch_conv(p, c.stem && pass == 0, mt, nt, hs[k]);
+            if (rc == TBN_OK) rc = tbn_launch_conv(p, c.stem && pass == 0, mt, nt, st);     // untimed first run of the candidate
             (void)hipEventRecord(ce[2 * ncand], st);
-            for (int k = 0; k < corun && rc == TBN_OK; ++k) rc = tbn_launch_conv(p, c.stem && pass == 0, mt, nt, hs[k]);
             if (rc == TBN_OK) rc = tbn_launch_conv(p, c.stem && pass == 0, mt, nt, st);
-            corun_join();
             (void)hipEventRecord(ce[2 * ncand + 1], st);
             cand[ncand++] = {mt, nt, p.stages, p.halo};
           }
+      corun_join();
       if (ncand > 0) (void)hipEventSynchronize(ce[2 * ncand - 1]);
+      if (corun) (void)hipStreamSynchronize(st);
       // A candidate is timed alone, back to back, on L2-warm operands; in the step its launches share the fabric with the
       // HBM-bound BN kernels of the other streams.  The per-tap gather forms (register-staged / LDS-DMA) move 2-6x the
       // bytes of the LDS-halo form on a 3x3 layer (profiles/r03_pmc_traffic.json): they must beat it by a margin to win.
@@ -1685,6 +1690,7 @@ int tbn_backbone_autotune(tbn_backbone_plan* P, int training, const tbn_backbone
       int bv = 1, bm = 1, bn = 1;
       Cand cand[kMaxCand];
       int ncand = 0;
+      corun_fork();
       for (int variant = 0; variant <= 2 && rc == TBN_OK; ++variant) {
         if (variant == 0 && (tbn_conv_halo_lds_bytes(pa, 1, 1) == 0 || tbn_conv_halo_lds_bytes(pb, 1, 1) == 0)) continue;
         for (int mt = 1; mt <= 2 && rc == TBN_OK; ++mt)
@@ -1693,17 +1699,18 @@ int tbn_backbone_autotune(tbn_backbone_plan* P, int training, const tbn_backbone
               continue;
             if (ncand >= kMaxCand) continue;
             if (mt * nt < min_tile) continue;   // experiment: no small tiles (a (2, 1) pair tile always exists)
-            rc = tbn_launch_conv_pair(pa, pb, variant, mt, nt, st);
-            corun_fork();
-            (void)hipEventRecord(ce[2 * ncand], st);
-            for (int k = 0; k < corun && rc == TBN_OK; ++k) rc = tbn_launch_conv_pair(pa, pb, variant, mt, nt, hs[k]);
+            for (int k = 0; k < corun && rc == TBN_OK; ++k)
+              for (int rep = 0; rep < 2 && rc == TBN_OK; ++rep) rc = tbn_launch_conv_pair(pa, pb, variant, mt, nt, hs[k]);
             if (rc == TBN_OK) rc = tbn_launch_conv_pair(pa, pb, variant, mt, nt, st);
-            corun_join();
+            (void)hipEventRecord(ce[2 * ncand], st);
+            if (rc == TBN_OK) rc = tbn_launch_conv_pair(pa, pb, variant, mt, nt, st);
             (void)hipEventRecord(ce[2 * ncand + 1], st);
             cand[ncand++] = {mt, nt, variant, 0};
           }
       }
+      corun_join();
       if (ncand > 0) (void)hipEventSynchronize(ce[2 * ncand - 1]);
+      if (corun) (void)hipStreamSynchronize(st);
       static const float pair_halo_bias = 0.01f * (float)tbn_env_int("TBN_TUNE_HALO_BIAS", 8, 0, 100);
       bool any_halo = false;   // cand[k].stages holds the pair variant: 0 = LDS-halo members (see the margin above)
       for (int k = 0; k < ncand; ++k) any_halo = any_halo || cand[k].stages == 0;
