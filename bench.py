@@ -275,6 +275,42 @@ def box_identity(device, smi=None):
     out["mfma_calibration"] = {"tflops": round(tf, 1), "frac_of_peak": round(tf / PEAK_FP32_MFMA_TFLOPS, 4),
                                "what": "v_mfma_f32_32x32x2_f32 register loop, 1024 workgroups x 4 waves, warm (after 35 ms "
                                        "of the same load), 8 launches of ~2.6 ms"}
+    # Round 6: boxes of the pool run the bare MFMA loop within 0.5 % of each other and the training step up to 7 % apart
+    # (profiles/r06_fast_box vs r06_slow_box) -- the step mixes MFMA work with ~60 GB of memory traffic.  Two more probes so that
+    # a line can say which kind of box it ran on: a streaming copy (1 GiB read + 1 GiB written per launch, beyond the
+    # Infinity Cache), alone, and the same MFMA burst WHILE that copy runs on a second stream.
+    try:
+        a = torch.empty(1 << 28, device=device, dtype=torch.float32)
+        b = torch.empty_like(a)
+        for _ in range(3):
+            b.copy_(a)
+        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        c0.record()
+        for _ in range(6):
+            b.copy_(a)
+        c1.record()
+        torch.cuda.synchronize()
+        copy_gbps = 6 * 2 * a.numel() * 4 / (c0.elapsed_time(c1) * 1e-3) / 1e9
+        side = torch.cuda.Stream(device=device)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(14):                                      # ~40 ms of copies beside the bursts below
+                b.copy_(a)
+        for _ in range(4):
+            call("tbn_diag_mfma_burst", ptr(sink), wg, iters, C.byref(fl), stream_ptr())
+        e0.record()
+        for _ in range(reps):
+            call("tbn_diag_mfma_burst", ptr(sink), wg, iters, C.byref(fl), stream_ptr())
+        e1.record()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        tf_mixed = reps * fl.value / (e0.elapsed_time(e1) * 1e-3) / 1e12
+        out["memory_calibration"] = {"copy_GBps": round(copy_gbps, 0), "mfma_tflops_beside_the_copy": round(tf_mixed, 1),
+                                     "what": "torch device copy of 1 GiB (read + written bytes counted), alone; the MFMA burst of "
+                                             "mfma_calibration while such copies run on a second stream"}
+        del a, b
+    except RuntimeError as e:       # out of memory on a shared card (rehearsals with several ranks per GPU): not fatal
+        out["memory_calibration"] = {"error": str(e)[:120]}
     return out
 
 
