@@ -7,9 +7,10 @@ nn.DataParallel's chunks had) and gradients are averaged with one collective per
 tensor -- the backbones keep their parameters in a few flat tensors (~41 MB per backbone) -- plus ONE
 for all small tensors (heads, biases, BN affine) packed into a flat buffer; a head tensor above 1 MB (the fusion Linear's
 weight) travels on its own: five all-reduces per step with three modalities.
-A backbone's all-reduce is issued as soon as autograd has accumulated its flat gradient, i.e. while the
-backbones whose backward was enqueued later are still running on their own HIP streams; the packed
-small-tensor collective goes last.  No collective on the data path.
+A backbone's flat gradient travels in buckets issued from INSIDE its backward as the engine reports slices final
+(tbn_backbone_grads.bucket_cb: inception_5a..5b, then 4a..4e), i.e. under the rest of that backward and under the other
+backbones' on their own HIP streams; the remaining prefixes and the packed small-tensor collective go at the end of
+backward, behind every bucket (collectives execute in issue order).  No collective on the data path.
 
 The collective SCHEDULE is the same on every rank by construction: the packed buffer always holds every
 small trainable parameter in registration order (a missing gradient travels as zeros), and a large tensor is
@@ -205,13 +206,15 @@ class DataParallel(nn.Module):
         self._fired.add(id(p))
         if self.overlap and p.grad is not None and p.grad.numel() >= self.SMALL and id(p) not in self._optional:
             _, op = self._reduce_op()
-            # buckets of this tensor that were exchanged from inside its backward are final already: only the prefix
-            # below them is left (the stem / 3a..3c weights of a backbone)
-            view = p.grad if id(p) not in self._bucketed else p.grad.view(-1)[:self._bucketed[id(p)]]
-            if view.numel():
-                self._pending.append((p, view, dist.all_reduce(view, op=op, group=self.process_group, async_op=True)))
+            if id(p) in self._bucketed:
+                # buckets of this tensor were exchanged from inside its backward: only the prefix below them is left (the
+                # stem / 3a..3c weights of a backbone, ~10 %).  It is final only when this backbone's WHOLE backward has run
+                # on the GPU -- about the end of the step, the three backward passes end together -- and collectives
+                # execute in issue order: issued here, it would hold up the buckets of the backbones whose backward is
+                # enqueued AFTER this one (ready long before) until then.  So the prefix waits for the end of backward.
+                self._pending.append((p, p.grad.view(-1)[:self._bucketed[id(p)]], None))
             else:
-                self._pending.append((p, view, None))
+                self._pending.append((p, p.grad, dist.all_reduce(p.grad, op=op, group=self.process_group, async_op=True)))
 
     def _begin_backward(self):
         """first gradient event of a synchronised backward (a hook or a bucket): fix what is optional in THIS step and
@@ -311,6 +314,12 @@ class DataParallel(nn.Module):
         small = [p for p in params if p.numel() < self.SMALL]
         works = [w for _, _, w in self._pending if w is not None]
         works += [dist.all_reduce(p.grad, op=op, group=self.process_group, async_op=True) for p in late_large]
+        # the prefixes of the bucketed tensors (see _on_grad_ready): now, behind every bucket of every backbone
+        for i, (p, view, w) in enumerate(self._pending):
+            if w is None and view.numel():
+                w = dist.all_reduce(view, op=op, group=self.process_group, async_op=True)
+                self._pending[i] = (p, view, w)
+                works.append(w)
         opt_list = [p for p in params if id(p) in optional]
         flat = None
         if small or opt_list:

@@ -511,7 +511,7 @@ class FlatFn(torch.autograd.Function):
         dw = (g.t() @ x).reshape(-1)
         waits, fn = [], ctx.module.grad_bucket_fn
         if fn is not None:
-            for lo, hi in ((64, 96), (32, 64)):            # what the engine's bucket_cb reports: suffixes of the flat tensor
+            for lo, hi in ((56, 96), (24, 56)):            # what the engine's bucket_cb reports: suffixes of the flat tensor
                 wt = fn(ctx.module.flat, dw, lo, hi)
                 if wt is not None: waits.append(wt)
         for wt in waits: wt()
@@ -553,12 +553,14 @@ def step(zero):
         assert torch.allclose(p.grad, q.grad, atol=1e-6), (n, float((p.grad - q.grad).abs().max()))
     assert model._pending == [] and model._bucketed == {} and not model._callback_queued
     return calls[n0:]
-# fresh gradients: per flat tensor two buckets from inside its backward (top slice first), the remaining prefix from its
-# gradient hook when the node returns -- the second module's node runs first (reverse of forward) -- then the packed
-# small tensors (two heads: 2 x (24 + 2) elements) last.  Same sequence on both ranks by construction.
+# fresh gradients: per flat tensor two buckets from inside its backward (top slice first; the second module's node runs
+# first: reverse of forward); the remaining prefixes (24 elements each) only at the END of backward, behind every bucket of
+# every module -- collectives execute in issue order, and a prefix is final only when its module's whole backward has run,
+# so issued from the hook it would hold up the next module's buckets -- then the packed small tensors (two heads:
+# 2 x (24 + 2) elements) last.  Same sequence on both ranks by construction.
 c = step(True)
-assert c == [32, 32, 32, 32, 32, 32, 52], c
-assert model.bucket_log == [(96, 64, 96), (96, 32, 64), (96, 64, 96), (96, 32, 64)], model.bucket_log
+assert c == [40, 32, 40, 32, 24, 24, 52], c
+assert model.bucket_log == [(96, 56, 96), (96, 24, 56), (96, 56, 96), (96, 24, 56)], model.bucket_log
 # accumulating into an existing .grad (no zero_grad): a bucket would average only the NEW part -> the whole tensor takes
 # the ordinary hook path, after the local accumulation
 c = step(False)
