@@ -302,6 +302,7 @@ class BNInception(nn.Module):
         # GEMM launch (include/tbn_hip.h TBN_BACKBONE_RIDERS); one-chain program only -- the engine ignores the flag in
         # branch mode -- and bit-identical to the stand-alone passes
         self.use_riders = True
+        self.stem_wgrad_last = False    # TBN_BACKBONE_STEM_WGRAD_LAST: see include/tbn_hip.h (bench.py --stem-wgrad-last)
         self._out_slot = None       # set by TBNModel for one forward: where the pooled (frames, 1024) feature is to be written
         self.plan_sync = None       # data parallel: object with is_source() / check(key, device) / broadcast(blob, device)
                                     # (DataParallel.PlanSync).  A forward that only SOME ranks run (validation on rank 0)
@@ -438,7 +439,7 @@ class BNInception(nn.Module):
         return {k: p.fingerprint() for k, p in self._plans.items()}
 
     def _engine_flags(self):
-        return 1 if self.use_riders else 0      # TBN_BACKBONE_RIDERS
+        return (1 if self.use_riders else 0) | (2 if self.stem_wgrad_last else 0)   # TBN_BACKBONE_RIDERS | TBN_BACKBONE_STEM_WGRAD_LAST
 
     def _side_stream_ptr(self):
         """the side stream that goes with the current stream (0: serial program; also while a graph is being captured --

@@ -132,6 +132,12 @@ class TBNModel(nn.Module):
             getattr(self, "Base_{}".format(m)).use_aux_stream = len(self.modality) == 1
             # likewise the branch-level side stream inside a backbone (include/tbn_hip.h, tbn_backbone_params.side_stream)
             getattr(self, "Base_{}".format(m)).use_branch_streams = len(self.modality) == 1
+            # with several modality streams the weight gradients of conv2_3x3 / conv2_3x3_reduce are issued AFTER conv1's
+            # pooled BN backward (TBN_BACKBONE_STEM_WGRAD_LAST: same kernels, bit-identical): every backward pass then ends
+            # on GEMMs, and its HBM-bound stem kernels sit under the other streams' GEMMs instead of beside their stem
+            # kernels -- the three passes end together (round 6, same-box alternations: config 4 -0.06 ... -0.18 ms, 7 of 8;
+            # config 3 -0.16 ms; profiles/r06_ab_stem_wgrad_last.txt)
+            getattr(self, "Base_{}".format(m)).stem_wgrad_last = len(self.modality) > 1
             if cfg.model.freeze_base:
                 self._freeze_base_model(m, freeze_mode=cfg.model.freeze_mode)
 

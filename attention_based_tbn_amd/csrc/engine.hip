@@ -1823,6 +1823,7 @@ int tbn_backbone_backward(const tbn_backbone_plan* P, const float* dfeatures, co
   // branch mode without an aux stream: the weight gradients share ONE split-K slab region, so those of the side chain
   // are issued on the launch stream once the side chain has been joined
   int deferred[8], ndef = 0;
+  const bool stem_last = !br && aux == nullptr && (prm->flags & TBN_BACKBONE_STEM_WGRAD_LAST) != 0;
   auto issue_wgrad = [&](const Conv& c, hipStream_t wst) -> int {
     tbn_prof_label(("wgrad " + c.parts[c.nparts - 1].name).c_str());
     WgradP wp;
@@ -2005,6 +2006,11 @@ int tbn_backbone_backward(const tbn_backbone_plan* P, const float* dfeatures, co
     } else if (br && o.side) {
       TBN_REQUIRE(ndef < 8, "backbone_backward: too many deferred weight gradients");
       deferred[ndef++] = o.idx;
+    } else if (stem_last && (o.idx == 1 || o.idx == 2)) {
+      // TBN_BACKBONE_STEM_WGRAD_LAST: the weight gradients of conv2_3x3 / conv2_3x3_reduce wait until conv1's pooled BN backward
+      // (HBM-bound, 0.3 ms exposed when the three backward passes end together) is enqueued -- a GEMM of this stream then
+      // runs while the other streams are in THEIR memory-bound tail.  Same kernels, same operands: bit-identical.
+      deferred[ndef++] = o.idx;
     } else {
       TBN_TRY(issue_wgrad(c, st));
     }
@@ -2029,6 +2035,10 @@ int tbn_backbone_backward(const tbn_backbone_plan* P, const float* dfeatures, co
       }
       TBN_TRY(tbn_launch_conv(p, 0, c.d_mt, c.d_nt, st, rd));
     }
+  }
+  if (stem_last) {
+    for (int k = 0; k < ndef; ++k) TBN_TRY(issue_wgrad(P->convs[deferred[k]], st_main));
+    ndef = 0;
   }
   TBN_REQUIRE(bpend_host < 0, "backbone_backward: a rider was left without its host launch (conv %d)", bpend_host);
   return TBN_OK;   // `join` joins the aux stream: everything the caller enqueues on `st` next sees the weight gradients

@@ -550,6 +550,9 @@ def main():
     ap.add_argument("--high-prio", default=None,
                     help="A/B: comma-separated modalities whose backbone stream gets the high HIP priority, or 'none' "
                          "(default: the model's, Audio)")
+    ap.add_argument("--stem-wgrad-last", default=None,
+                    help="A/B: comma-separated modalities whose backbone issues the weight gradients of conv2_3x3 / conv2_3x3_reduce "
+                         "AFTER conv1's pooled BN backward (TBN_BACKBONE_STEM_WGRAD_LAST; default: none)")
     ap.add_argument("--share-stream", default=None,
                     help="A/B: 'Flow:RGB,...' -- a modality's backbone runs on another modality's stream (default: none)")
     args = ap.parse_args()
@@ -676,6 +679,9 @@ def main():
     core.multi_stream = multi
     if args.high_prio is not None:
         core.high_priority_modalities = tuple(x for x in args.high_prio.split(",") if x and x != "none")
+    if args.stem_wgrad_last:
+        for b_, m in zip(bases, modality):
+            b_.stem_wgrad_last = m in args.stem_wgrad_last.split(",")
     if args.share_stream:
         core.shared_streams = dict(item.split(":") for item in args.share_stream.split(","))
     aux = [b_.use_aux_stream and not args.no_aux_stream for b_ in bases]   # the model's own policy unless switched off

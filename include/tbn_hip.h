@@ -95,6 +95,10 @@ typedef struct {
                                  the conv launches. */
 } tbn_backbone_params;
 #define TBN_BACKBONE_RIDERS 1
+#define TBN_BACKBONE_STEM_WGRAD_LAST 2   /* one-chain backward without aux stream: the weight gradients of conv2_3x3 and
+                                            conv2_3x3_reduce are issued after conv1's pooled BN backward instead of before it
+                                            (same kernels, bit-identical results; a scheduling choice between the replicas'
+                                            streams) */
 
 typedef struct {
   float* dweight;             /* same layout as weight; fully overwritten */

@@ -895,6 +895,39 @@ def _lone_backbone_for_capture():
     return net, x, step
 
 
+def test_stem_weight_gradients_last_is_bit_identical():
+    """TBN_BACKBONE_STEM_WGRAD_LAST (include/tbn_hip.h; what TBNModel sets for multi-modality models): the weight gradients of
+    conv2_3x3 / conv2_3x3_reduce issued after conv1's pooled BN backward instead of before it -- a pure reordering of
+    launches on one stream (the deferred launches read dy and z buffers nothing overwrites in between): outputs, every
+    gradient and the running statistics must be bit-identical, for every stem form (RGB / audio space-to-depth, flow row runs)"""
+    from attention_based_tbn_amd.core.models.bn_inception import BNInception
+    for cin, N, H, W in ((3, 4, 224, 224), (10, 3, 96, 96), (1, 3, 128, 256)):
+        torch.manual_seed(cin)
+        net = BNInception(1000, cin).to(DEV)
+        net.set_bn_trainable(True, True)
+        net.use_aux_stream = net.use_branch_streams = False
+        x = torch.randn(N, cin, H, W, device=DEV)
+        rm0, rv0 = net.running_mean.clone(), net.running_var.clone()
+
+        def step(flag):
+            net.train()
+            net.stem_wgrad_last = flag
+            net.running_mean.copy_(rm0)
+            net.running_var.copy_(rv0)
+            net.zero_grad(set_to_none=True)
+            out = net(x)
+            (out.square().mean() + out.sum() * 1e-3).backward()
+            torch.cuda.synchronize()
+            return [out.detach().clone(), net.flat_weight.grad.clone(), net.flat_bias.grad.clone(), net.bn_weight_first.grad.clone(),
+                    net.bn_weight_rest.grad.clone(), net.bn_bias_rest.grad.clone(), net.running_mean.clone(), net.running_var.clone()]
+
+        ref = step(False)
+        assert float(ref[1].abs().max()) > 0
+        for rep in range(2):
+            got = step(True)
+            assert all(torch.equal(a, b) for a, b in zip(got, ref)), (cin, rep)
+
+
 def test_capture_guard_refuses_aux_stream_and_leaves_the_plan_intact(monkeypatch):
     """`tbn_backbone_backward` refuses an aux stream while its launch stream is capturing (TBN_ERR_UNSUPPORTED: the fix
     for the SIGSEGV of nested capture forks in ROCm 7.x's hipStreamEndCapture, profiles/r03_graph_capture_multi_aux_rocgdb.log).
