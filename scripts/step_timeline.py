@@ -129,3 +129,30 @@ print("%-22s %8s %10s %12s %12s %10s" % ("family", "kernels", "sum ms", "hidden 
 for fam in sorted(tot, key=lambda k: -tot[k]):
     print("%-22s %8d %10.3f %12.3f %12.3f %10.3f" % (fam, cnt[fam], tot[fam] / 1e6, hidden[fam] / 1e6, exposed[fam] / 1e6,
                                                      alone[fam] / 1e6))
+# optional third argument "bins": the same partition per millisecond of the step -- where the periods with 0 or 1 GEMM in flight lie
+if len(sys.argv) > 3 and sys.argv[3] == "bins":
+    nb = int(wall // 1_000_000) + 1
+    share = [[0.0] * 5 for _ in range(nb)]
+    names = [defaultdict(float) for _ in range(nb)]
+    ng = 0
+    last3 = t0
+    for t, dk, dg in ev2:
+        s = last3
+        while s < t:                      # spread [last3, t) over the bins it crosses
+            b = int((s - t0) // 1_000_000)
+            e = min(t, t0 + (b + 1) * 1_000_000)
+            share[min(b, nb - 1)][min(ng, 4)] += e - s
+            s = e
+        ng += dg
+        last3 = t
+    for s, e, n, q in step:
+        if family(n) == "gemm":
+            continue
+        b = min(int((s - t0) // 1_000_000), nb - 1)
+        names[b][family(n)] += e - s
+    print("per millisecond: share of the bin with 0 / 1 / 2 / 3 / 4+ conv GEMMs in flight | largest non-GEMM families started in the bin (kernel ms)")
+    for b in range(nb):
+        tot_b = sum(share[b]) or 1.0
+        top = sorted(names[b].items(), key=lambda kv: -kv[1])[:3]
+        print("%3d ms  " % b + " ".join("%5.1f" % (100.0 * v / tot_b) for v in share[b]) + "  | " +
+              ", ".join("%s %.2f" % (k, v / 1e6) for k, v in top))
