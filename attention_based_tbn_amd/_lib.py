@@ -89,6 +89,7 @@ SIGNATURES = {
     "tbn_backbone_autotune": (c_i, [C.c_void_p, c_i, C.POINTER(BackboneParams), c_fp, c_sz, c_fp]),
     "tbn_backbone_backward": (c_i, [C.c_void_p, c_fp, C.POINTER(BackboneParams), C.POINTER(BackboneGrads), c_fp,
                                     c_sz, c_fp]),
+    "tbn_backbone_flip_weights": (c_i, [C.c_void_p, C.POINTER(BackboneParams), c_fp, c_sz, c_fp]),
     "tbn_conv2d_fwd": (c_i, [c_fp, c_i, c_fp, c_fp, c_fp, c_i] + [c_i] * 10 + [c_fp, c_fp, c_fp, c_fp]),
     "tbn_conv2d_stat_tiles": (c_i, [c_i] * 8),
     "tbn_conv2d_fwd_tile": (c_i, [c_fp, c_i, c_fp, c_fp, c_fp, c_i] + [c_i] * 10 + [c_fp, c_i, c_i, c_fp]),

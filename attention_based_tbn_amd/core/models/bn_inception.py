@@ -149,6 +149,11 @@ class _Token:
     pass
 
 
+class _Flip:
+    """state of the data-gradient weight copy of one training forward (BNInception.flip_weights_early)"""
+    __slots__ = ("plan", "ws", "weight", "version", "done", "__weakref__")
+
+
 class _BackboneFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, g0, g1, b0, b1, module, freq_only):
@@ -209,6 +214,9 @@ class _BackboneFn(torch.autograd.Function):
         if need_grad:
             ctx.plan, ctx.ws, ctx.token, ctx.module, ctx.freq_only = plan, ws, token, module, freq_only
             ctx.save_for_backward(weight, bias, gamma, beta)
+            f = ctx.flip = _Flip()
+            f.plan, f.ws, f.weight, f.version, f.done = plan, ws, weight, weight._version, False
+            module._last_flip = weakref.ref(f)
         ctx.need_grad = need_grad
         ctx.eval_mode = not training
         return out
@@ -238,8 +246,11 @@ class _BackboneFn(torch.autograd.Function):
         bn_first, bn_rest = need[3] or need[5], need[4] or need[6]
         dg = torch.zeros_like(gamma) if (bn_first or bn_rest) else None
         dbe = torch.zeros_like(beta) if (bn_first or bn_rest) else None
+        # the data-gradient weight copy was made early (flip_weights_early) and the weights are still the ones it read
+        flipped = ctx.flip.done and ctx.flip.version == weight._version
         prm = BackboneParams(ptr(weight), ptr(bias), ptr(gamma), ptr(beta), ptr(module.running_mean),
-                             ptr(module.running_var), 0.1, 1e-5, module._side_stream_ptr(), module._engine_flags())
+                             ptr(module.running_var), 0.1, 1e-5, module._side_stream_ptr(),
+                             module._engine_flags() | (4 if flipped else 0))
         aux = 0
         # inside a stream capture (torch.cuda.graph of a whole step) the weight gradients stay on the launch stream: the
         # engine refuses an aux stream there (TBN_ERR_UNSUPPORTED -- a capture that forks from an already forked stream
@@ -303,6 +314,7 @@ class BNInception(nn.Module):
         # branch mode -- and bit-identical to the stand-alone passes
         self.use_riders = True
         self.stem_wgrad_last = False    # TBN_BACKBONE_STEM_WGRAD_LAST: see include/tbn_hip.h (bench.py --stem-wgrad-last)
+        self._last_flip = None          # weak reference to the last training forward's _Flip (flip_weights_early)
         self._out_slot = None       # set by TBNModel for one forward: where the pooled (frames, 1024) feature is to be written
         self.plan_sync = None       # data parallel: object with is_source() / check(key, device) / broadcast(blob, device)
                                     # (DataParallel.PlanSync).  A forward that only SOME ranks run (validation on rank 0)
@@ -437,6 +449,22 @@ class BNInception(nn.Module):
         """{(frames, H, W): hex fingerprint of the plan's launch choices} -- equal across the replicas of a data-parallel
         job once `plan_sync` is set; `bench.py` prints them so that a slow box can be told from a different plan"""
         return {k: p.fingerprint() for k, p in self._plans.items()}
+
+    def flip_weights_early(self):
+        """Launch, on the CURRENT stream (which must be the one the last training forward of this module ran on), the
+        flipped / transposed data-gradient weight copy its backward pass starts with (tbn_backbone_flip_weights,
+        include/tbn_hip.h).  TBNModel calls this right after joining the modality streams for the heads: the copy
+        (~0.1 ms per backbone, HBM-bound) then runs beside the heads' ~20 small dependent launches instead of between
+        them and the first backward GEMM.  The backward pass skips its own copy only if the weights are unchanged
+        (`_version`); no-op when the last forward needs no backward or while a graph is being captured."""
+        f = self._last_flip() if getattr(self, "_last_flip", None) is not None else None
+        self._last_flip = None
+        if f is None or f.done or f.weight._version != f.version or torch.cuda.is_current_stream_capturing():
+            return False
+        prm = BackboneParams(ptr(f.weight), 0, 0, 0, 0, 0, 0.1, 1e-5, 0, 0)
+        call("tbn_backbone_flip_weights", f.plan.handle, C.byref(prm), ptr(f.ws), f.ws.numel(), stream_ptr())
+        f.done = True
+        return True
 
     def _engine_flags(self):
         return (1 if self.use_riders else 0) | (2 if self.stem_wgrad_last else 0)   # TBN_BACKBONE_RIDERS | TBN_BACKBONE_STEM_WGRAD_LAST

@@ -116,6 +116,10 @@ class TBNModel(nn.Module):
         # Audio+Flow 36.14 / Flow 36.56 / none 36.38).  Plain attributes, set before the first forward: A/B runs change them
         # from their own scripts (bench.py --high-prio / --share-stream); the product reads no environment variable
         self.high_priority_modalities = ("Audio",)
+        # the backbones' data-gradient weight copies (0.1 ms each, the first launch of a backward pass) are issued right after
+        # the modality streams are joined for the heads, so they run beside the heads' small launches instead of in the
+        # serial turn between forward and backward (BNInception.flip_weights_early; bench.py --no-early-flip for the A/B)
+        self.flip_weights_early = True
         self.shared_streams = {}          # {"Flow": "RGB"}: Flow's backbone runs on RGB's stream (fewer concurrent chains)
         if cfg.model.agg_type.lower() == "avg":
             self.agg_type = "avg"
@@ -260,6 +264,12 @@ class TBNModel(nn.Module):
         for m in self.modality:
             main.wait_stream(self._streams[m])
             raw[m].record_stream(main)
+        if self.flip_weights_early and torch.is_grad_enabled():
+            # behind the join: the heads (on `main`) do not wait for these launches; each backbone's backward pass, which
+            # autograd replays on the same modality stream, finds its data-gradient weight copy done
+            for m in self.modality:
+                with torch.cuda.stream(self._streams[m]):
+                    getattr(self, "Base_{}".format(m)).flip_weights_early()
         return raw
 
     def forward(self, input):

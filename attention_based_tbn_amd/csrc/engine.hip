@@ -1759,6 +1759,13 @@ int tbn_backbone_autotune(tbn_backbone_plan* P, int training, const tbn_backbone
   return rc;
 }
 
+int tbn_backbone_flip_weights(const tbn_backbone_plan* P, const tbn_backbone_params* prm, void* workspace, size_t workspace_bytes,
+                              void* stream) {
+  TBN_REQUIRE(P && prm && workspace && prm->weight, "backbone_flip_weights: null argument");
+  TBN_REQUIRE(workspace_bytes >= P->total_bytes_train, "backbone_flip_weights: workspace too small (training workspace expected)");
+  return tbn_launch_weight_flip_transpose_all(prm->weight, (float*)workspace + P->wt_off, P->flip, (hipStream_t)stream);
+}
+
 int tbn_backbone_backward(const tbn_backbone_plan* P, const float* dfeatures, const tbn_backbone_params* prm,
                           const tbn_backbone_grads* g, void* workspace, size_t workspace_bytes, void* stream) {
   TBN_REQUIRE(P && dfeatures && prm && g && workspace, "backbone_backward: null argument");
@@ -1813,7 +1820,8 @@ int tbn_backbone_backward(const tbn_backbone_plan* P, const float* dfeatures, co
     return buf == P->out_buf ? dfeatures : ws + P->bufs[buf].doff;
   };
 
-  TBN_TRY(tbn_launch_weight_flip_transpose_all(prm->weight, ws + P->wt_off, P->flip, st));
+  if ((prm->flags & TBN_BACKBONE_WEIGHTS_FLIPPED) == 0)      // else: tbn_backbone_flip_weights ran on this workspace since the forward
+    TBN_TRY(tbn_launch_weight_flip_transpose_all(prm->weight, ws + P->wt_off, P->flip, st));
   const std::vector<Op>& prog = br ? P->ops_b : P->ops;
   const hipStream_t st_main = st;
   const bool use_riders = !br && (prm->flags & TBN_BACKBONE_RIDERS) != 0 && !tbn_prof_enabled() && !P->riders.empty();

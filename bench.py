@@ -552,7 +552,11 @@ def main():
                          "(default: the model's, Audio)")
     ap.add_argument("--stem-wgrad-last", default=None,
                     help="A/B: comma-separated modalities whose backbone issues the weight gradients of conv2_3x3 / conv2_3x3_reduce "
-                         "AFTER conv1's pooled BN backward (TBN_BACKBONE_STEM_WGRAD_LAST; default: none)")
+                         "AFTER conv1's pooled BN backward (TBN_BACKBONE_STEM_WGRAD_LAST; default: the model's -- all of them when "
+                         "there are several), or 'none'")
+    ap.add_argument("--no-early-flip", action="store_true",
+                    help="A/B: the backbones' data-gradient weight copies at the start of each backward pass instead of right after "
+                         "the modality streams are joined for the heads (TBNModel.flip_weights_early)")
     ap.add_argument("--share-stream", default=None,
                     help="A/B: 'Flow:RGB,...' -- a modality's backbone runs on another modality's stream (default: none)")
     args = ap.parse_args()
@@ -682,6 +686,8 @@ def main():
     if args.stem_wgrad_last:
         for b_, m in zip(bases, modality):
             b_.stem_wgrad_last = m in args.stem_wgrad_last.split(",")
+    if args.no_early_flip:
+        core.flip_weights_early = False
     if args.share_stream:
         core.shared_streams = dict(item.split(":") for item in args.share_stream.split(","))
     aux = [b_.use_aux_stream and not args.no_aux_stream for b_ in bases]   # the model's own policy unless switched off

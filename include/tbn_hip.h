@@ -99,6 +99,10 @@ typedef struct {
                                             conv2_3x3_reduce are issued after conv1's pooled BN backward instead of before it
                                             (same kernels, bit-identical results; a scheduling choice between the replicas'
                                             streams) */
+#define TBN_BACKBONE_WEIGHTS_FLIPPED 4   /* tbn_backbone_backward only: the flipped / transposed data-gradient weights in the
+                                            workspace are current (tbn_backbone_flip_weights ran on this workspace, on the same
+                                            stream, after the matching forward and the weights have not changed since): the pass
+                                            does not launch the flip itself */
 
 typedef struct {
   float* dweight;             /* same layout as weight; fully overwritten */
@@ -195,6 +199,13 @@ int tbn_backbone_autotune(tbn_backbone_plan* plan, int training, const tbn_backb
 int tbn_backbone_backward(const tbn_backbone_plan* plan, const float* dfeatures,
                           const tbn_backbone_params* params, const tbn_backbone_grads* grads, void* workspace,
                           size_t workspace_bytes, void* stream);
+/* The first launch of tbn_backbone_backward on its own: the flipped / transposed copy of every data-gradient weight
+ * (what autograd's conv backward gets from cuDNN implicitly; reference: loss.backward(), core/tools/train.py:86) into the
+ * training workspace.  It depends on the weights only, so a caller with several backbones on several streams can issue it on
+ * each backbone's stream right after the streams were joined for the heads -- it then runs beside the heads' small kernels
+ * instead of between them and the first backward GEMM -- and pass TBN_BACKBONE_WEIGHTS_FLIPPED to the backward pass. */
+int tbn_backbone_flip_weights(const tbn_backbone_plan* plan, const tbn_backbone_params* params, void* workspace,
+                              size_t workspace_bytes, void* stream);
 
 /* ---- single operators (same kernels the engine uses; used by the heads and the parity tests) ---- */
 

@@ -928,6 +928,89 @@ def test_stem_weight_gradients_last_is_bit_identical():
             assert all(torch.equal(a, b) for a, b in zip(got, ref)), (cin, rep)
 
 
+def test_early_weight_flip_is_bit_identical_and_only_trusted_while_the_weights_are_unchanged():
+    """TBNModel.flip_weights_early / BNInception.flip_weights_early (tbn_backbone_flip_weights + TBN_BACKBONE_WEIGHTS_FLIPPED,
+    include/tbn_hip.h): the data-gradient weight copy launched right after the modality streams are joined instead of at the
+    start of each backward pass.  Same kernel on the same weights: every gradient of a config-4 train step is bit-identical
+    with the switch off; the library timeline shows one copy per backbone and step either way, before the heads' kernels when
+    early; a lone backbone: the copy is launched at most once per training forward and never for a no-grad forward."""
+    import ctypes as C
+    from attention_based_tbn_amd import _lib
+    from attention_based_tbn_amd.config import load_config, get_modality
+    from attention_based_tbn_amd.core.models import build_model
+    from attention_based_tbn_amd.core.models.bn_inception import BNInception
+    cfg = load_config(["model.attention.enable=False", "data.audio.audio_length=1.279", "data.sampling=async", "model.fusion_dropout=0"])
+    modality = get_modality(cfg)
+    torch.manual_seed(0)
+    model, crit, _ = build_model(cfg, modality, DEV)
+    core = model.module if hasattr(model, "module") else model
+    assert core.flip_weights_early is True
+    g = torch.Generator(device="cuda").manual_seed(1)
+    B, n = 2, 3
+    inp = {"RGB": torch.rand(B, n, 3, 96, 96, device=DEV, generator=g) - 0.45,
+           "Flow": torch.rand(B, n, 10, 96, 96, device=DEV, generator=g) - 0.5,
+           "Audio": torch.randn(B, n, 1, 96, 128, device=DEV, generator=g) * 3 - 6}
+    tgt = {"class": {"verb": torch.randint(0, 125, (B,), device=DEV), "noun": torch.randint(0, 352, (B,), device=DEV)}}
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+    lib = _lib.lib()
+
+    def step(early, trace=None):
+        model.load_state_dict(state)
+        model.train()
+        core.flip_weights_early = early
+        model.zero_grad(set_to_none=True)
+        if trace:
+            lib.tbn_timeline_enable(1)
+        out = model(inp)
+        loss, _ = model.get_loss(crit, tgt, out, 0)
+        loss["total"].backward()
+        torch.cuda.synchronize()
+        if trace:
+            assert lib.tbn_timeline_dump(trace.encode()) == 0
+            lib.tbn_timeline_enable(0)
+        return {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+
+    step(True)                       # tunes the plans
+    ref = step(False)
+    import csv, tempfile, os
+    for early in (True, False):
+        path = os.path.join(tempfile.mkdtemp(), "tl.csv")
+        got = step(early, path)
+        assert got.keys() == ref.keys()
+        for k in ref:
+            assert torch.equal(got[k], ref[k]), (early, k)
+        rows = sorted((int(r["Start_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(path)))
+        names = [nm for _, nm in rows]
+        flips = [i for i, nm in enumerate(names) if "weight_flip_transpose_all" in nm]
+        ce = [i for i, nm in enumerate(names) if "ce_heads_bwd" in nm]
+        assert len(flips) == 3 and len(ce) == 1, (early, len(flips), len(ce))
+        if not early:
+            assert min(flips) > ce[0]        # the backward passes' own first launch
+    # one backbone on its own
+    torch.manual_seed(2)
+    net = BNInception(1000, 3).to(DEV)
+    net.set_bn_trainable(True, True)
+    net.use_aux_stream = net.use_branch_streams = False
+    x = torch.randn(3, 3, 96, 96, device=DEV)
+
+    def lone(early):
+        net.train()
+        net.zero_grad(set_to_none=True)
+        out = net(x)
+        if early:
+            assert net.flip_weights_early() is True and net.flip_weights_early() is False      # once per training forward
+        (out.square().mean()).backward()
+        torch.cuda.synchronize()
+        return net.flat_weight.grad.clone(), net.flat_bias.grad.clone()
+
+    a = lone(False)
+    for _ in range(2):
+        b = lone(True)
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    with torch.no_grad():
+        assert net(x) is not None and net.flip_weights_early() is False    # no backward to prepare
+
+
 def test_capture_guard_refuses_aux_stream_and_leaves_the_plan_intact(monkeypatch):
     """`tbn_backbone_backward` refuses an aux stream while its launch stream is capturing (TBN_ERR_UNSUPPORTED: the fix
     for the SIGSEGV of nested capture forks in ROCm 7.x's hipStreamEndCapture, profiles/r03_graph_capture_multi_aux_rocgdb.log).
