@@ -872,7 +872,9 @@ def main():
                        "streams": {"modality_streams": bool(multi and len(modality) > 1),
                                    "weight_gradient_stream": [m for m, a_ in zip(modality, aux) if a_],
                                    "branch_streams": [m for m, b_ in zip(modality, branch) if b_],
-                                   "riders": [m for m, b_ in zip(modality, bases) if b_.use_riders]},
+                                   "riders": [m for m, b_ in zip(modality, bases) if b_.use_riders],
+                                   "stem_weight_gradients_last": [m for m, b_ in zip(modality, bases) if b_.stem_wgrad_last],
+                                   "early_weight_flip": bool(getattr(core, "flip_weights_early", False)) and multi and len(modality) > 1},
                        **({"inputs": "pinned host memory, PCIe copy every step (diagnostic)"} if args.host_inputs else {}),
                        **({"audio_input": "waveform (30695 samples), STFT kernel inside the timed step"} if args.stft_inputs else {})},
             "roofline": roofline,
