@@ -928,7 +928,7 @@ def test_stem_weight_gradients_last_is_bit_identical():
             assert all(torch.equal(a, b) for a, b in zip(got, ref)), (cin, rep)
 
 
-def test_early_weight_flip_is_bit_identical_and_only_trusted_while_the_weights_are_unchanged():
+def test_early_weight_flip_is_bit_identical():
     """TBNModel.flip_weights_early / BNInception.flip_weights_early (tbn_backbone_flip_weights + TBN_BACKBONE_WEIGHTS_FLIPPED,
     include/tbn_hip.h): the data-gradient weight copy launched right after the modality streams are joined instead of at the
     start of each backward pass.  Same kernel on the same weights: every gradient of a config-4 train step is bit-identical
