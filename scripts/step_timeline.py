@@ -156,3 +156,28 @@ if len(sys.argv) > 3 and sys.argv[3] == "bins":
         top = sorted(names[b].items(), key=lambda kv: -kv[1])[:3]
         print("%3d ms  " % b + " ".join("%5.1f" % (100.0 * v / tot_b) for v in share[b]) + "  | " +
               ", ".join("%s %.2f" % (k, v / 1e6) for k, v in top))
+# optional third argument "turn": the serial turn between forward and backward of every complete step in the trace -- from the end of
+# the last forward backbone GEMM to the start of the first backward backbone GEMM (backbone GEMMs: conv kernels on a modality
+# stream, i.e. not on the null stream the heads run on) -- and the kernels of the selected step's turn
+if len(sys.argv) > 3 and sys.argv[3] == "turn":
+    def backbone_gemm(r):
+        return family(r[2]) == "gemm" and r[3] not in ("(nil)", "0x0", "")
+    turns = []
+    for gi in range(1, len(groups)):
+        sa, sb = groups[gi - 1][-1] + 1, groups[gi][-1] + 1
+        st_rows = rows[sa:sb]
+        ce = [r for r in st_rows if "ce_heads_bwd" in r[2]]
+        big = [r for r in st_rows if backbone_gemm(r)]
+        if not ce or not big:
+            continue
+        lf = max(r[1] for r in big if r[0] < ce[0][0])
+        fb = min(r[0] for r in big if r[0] > ce[0][0])
+        turns.append((fb - lf) / 1e3)
+    ce = [r for r in step if "ce_heads_bwd" in r[2]][0]
+    big = [r for r in step if backbone_gemm(r)]
+    lf = max(r[1] for r in big if r[0] < ce[0])
+    fb = min(r[0] for r in big if r[0] > ce[0])
+    print("turn (last forward backbone GEMM end -> first backward backbone GEMM start), us per step: " + " ".join("%.0f" % t for t in turns))
+    for s, e, n, q in step:
+        if lf - 50_000 <= s <= fb + 50_000:
+            print("%9.3f %7.1f us q=%s %s" % ((s - t0) / 1e6, (e - s) / 1e3, q[-6:], n.replace("void ", "")[:70]))
