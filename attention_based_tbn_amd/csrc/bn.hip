@@ -488,7 +488,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_pooled2x2_kernel(PoolBlk pb,
       const int iy = 2 * by + (k >> 1), ix = 2 * bx + (k & 1);
       if (iy < pb.H && ix < pb.W) {
         const size_t off = ((size_t)((int)n * pb.H + iy) * pb.W + ix) * C + c;
-        const float4 v = *reinterpret_cast<const float4*>(y + off);
+        const float4 v = tbn_ld4<(TBN_BN_NT & 8) != 0>(y + off);
         float4 o;
         o.x = fmaf(ca.x, fmaf(v.x, sc.x, sh.x) > 0.f ? g[k].x : 0.f, fmaf(cb.x, v.x, cc.x));
         o.y = fmaf(ca.y, fmaf(v.y, sc.y, sh.y) > 0.f ? g[k].y : 0.f, fmaf(cb.y, v.y, cc.y));

@@ -1445,17 +1445,16 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   __shared__ float4 red[256];
   const int o = threadIdx.x % NO, g = threadIdx.x / NO;
   const int i = blockIdx.x * NO + o;
-  const float4* p4 = reinterpret_cast<const float4*>(part);
   float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
   if (i < n4) {
     int s = g;
     for (; s + SG < splits; s += 2 * SG) {
-      const float4 u = p4[(size_t)s * slab4 + i], v = p4[(size_t)(s + SG) * slab4 + i];
+      const float4 u = tbn_ld4<(TBN_BN_NT & 8) != 0>(part + 4 * ((size_t)s * slab4 + i)), v = tbn_ld4<(TBN_BN_NT & 8) != 0>(part + 4 * ((size_t)(s + SG) * slab4 + i));
       a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
       b.x += v.x; b.y += v.y; b.z += v.z; b.w += v.w;
     }
     if (s < splits) {
-      const float4 u = p4[(size_t)s * slab4 + i];
+      const float4 u = tbn_ld4<(TBN_BN_NT & 8) != 0>(part + 4 * ((size_t)s * slab4 + i));
       a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
     }
     a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;

@@ -120,3 +120,35 @@ struct CSeg {
   int ld;
   int col_begin;
 };
+
+#ifdef __HIPCC__
+// Cache policy of the once-read streams of the HBM-bound passes (-DTBN_BN_NT=<bits> for A/B builds; shipped: 11).  A non-temporal
+// load asks L2 not to keep the line: the 31 GB per step these passes move then displace less of what the conv GEMMs of the other
+// modality streams share through L2 (weights, the row panels sibling workgroups re-read).  bit 0: the forward apply's y (not read
+// again before the backward pass); bit 1: the backward apply's dz and y (their last use); bit 3: y in the stem's pooled
+// BN-backward apply, the split-K slabs in their reduce, weights / gradients / momenta in the optimiser; bit 2: the STORES of
+// z / dy -- their consumers follow at once, measured slower, off.  Same values either way (a cache hint): bit-identical results.
+// Round 6, same-box alternations: config 4 -0.06 ... -0.09 ms per step (6 of 7), config 3 -0.2 ms, config 2 -0.05 ms
+// (profiles/r06_ab_nontemporal_loads.txt).
+#ifndef TBN_BN_NT
+#define TBN_BN_NT 11
+#endif
+typedef float tbn_f32x4_nt __attribute__((ext_vector_type(4)));
+template <bool NT>
+__device__ __forceinline__ float4 tbn_ld4(const float* p) {
+  if (NT) {
+    const tbn_f32x4_nt v = __builtin_nontemporal_load(reinterpret_cast<const tbn_f32x4_nt*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+  }
+  return *reinterpret_cast<const float4*>(p);
+}
+template <bool NT>
+__device__ __forceinline__ void tbn_st4(float* p, const float4 o) {
+  if (NT) {
+    tbn_f32x4_nt v = {o.x, o.y, o.z, o.w};
+    __builtin_nontemporal_store(v, reinterpret_cast<tbn_f32x4_nt*>(p));
+  } else {
+    *reinterpret_cast<float4*>(p) = o;
+  }
+}
+#endif

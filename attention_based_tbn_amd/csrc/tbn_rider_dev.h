@@ -23,7 +23,7 @@ __device__ __forceinline__ void tbn_bn_apply_rows(const float* __restrict__ y, i
   for (; p + 3 * RP < p1; p += 4 * RP) {
     float4 v[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) v[k] = *reinterpret_cast<const float4*>(yp + k * ystep);
+    for (int k = 0; k < 4; ++k) v[k] = tbn_ld4<(TBN_BN_NT & 1) != 0>(yp + k * ystep);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       float4 o;
@@ -31,19 +31,19 @@ __device__ __forceinline__ void tbn_bn_apply_rows(const float* __restrict__ y, i
       o.y = fmaxf(fmaf(v[k].y, sc.y, sh.y), 0.f);
       o.z = fmaxf(fmaf(v[k].z, sc.z, sh.z), 0.f);
       o.w = fmaxf(fmaf(v[k].w, sc.w, sh.w), 0.f);
-      *reinterpret_cast<float4*>(zp + k * zstep) = o;
+      tbn_st4<(TBN_BN_NT & 4) != 0>(zp + k * zstep, o);
     }
     yp += 4 * ystep;
     zp += 4 * zstep;
   }
   for (; p < p1; p += RP) {
-    const float4 v = *reinterpret_cast<const float4*>(yp);
+    const float4 v = tbn_ld4<(TBN_BN_NT & 1) != 0>(yp);
     float4 o;
     o.x = fmaxf(fmaf(v.x, sc.x, sh.x), 0.f);
     o.y = fmaxf(fmaf(v.y, sc.y, sh.y), 0.f);
     o.z = fmaxf(fmaf(v.z, sc.z, sh.z), 0.f);
     o.w = fmaxf(fmaf(v.w, sc.w, sh.w), 0.f);
-    *reinterpret_cast<float4*>(zp) = o;
+    tbn_st4<(TBN_BN_NT & 4) != 0>(zp, o);
     yp += ystep;
     zp += zstep;
   }
@@ -80,17 +80,17 @@ __device__ __forceinline__ void tbn_bn_bwd_apply_rows(const float* __restrict__ 
     float4 d[4], v[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      d[k] = *reinterpret_cast<const float4*>(dp + k * dstep);
-      v[k] = *reinterpret_cast<const float4*>(yp + k * ystep);
+      d[k] = tbn_ld4<(TBN_BN_NT & 2) != 0>(dp + k * dstep);
+      v[k] = tbn_ld4<(TBN_BN_NT & 2) != 0>(yp + k * ystep);
     }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) *reinterpret_cast<float4*>(op + k * ystep) = one(d[k], v[k]);
+    for (int k = 0; k < 4; ++k) tbn_st4<(TBN_BN_NT & 4) != 0>(op + k * ystep, one(d[k], v[k]));
     dp += 4 * dstep;
     yp += 4 * ystep;
     op += 4 * ystep;
   }
   for (; p < p1; p += RP) {
-    *reinterpret_cast<float4*>(op) = one(*reinterpret_cast<const float4*>(dp), *reinterpret_cast<const float4*>(yp));
+    tbn_st4<(TBN_BN_NT & 4) != 0>(op, one(tbn_ld4<(TBN_BN_NT & 2) != 0>(dp), tbn_ld4<(TBN_BN_NT & 2) != 0>(yp)));
     dp += dstep;
     yp += ystep;
     op += ystep;

@@ -145,10 +145,10 @@ __global__ __launch_bounds__(256) void opt_sgd_kernel(OptTab tab, float lr, floa
   };
   const size_t end4 = tab.vec[l] ? beg + ((end - beg) & ~(size_t)3) : beg;
   for (size_t i = beg + (size_t)threadIdx.x * 4; i < end4; i += 1024) {
-    const float4 pv = *reinterpret_cast<const float4*>(p + i);
-    const float4 gv = *reinterpret_cast<const float4*>(g + i);
+    const float4 pv = tbn_ld4<(TBN_BN_NT & 8) != 0>(p + i);
+    const float4 gv = tbn_ld4<(TBN_BN_NT & 8) != 0>(g + i);
     float4 mv = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (m != nullptr) mv = *reinterpret_cast<const float4*>(m + i);
+    if (m != nullptr) mv = tbn_ld4<(TBN_BN_NT & 8) != 0>(m + i);
     float4 pn, mn;
     upd(pv.x, gv.x, mv.x, pn.x, mn.x);
     upd(pv.y, gv.y, mv.y, pn.y, mn.y);
